@@ -1,0 +1,87 @@
+/* vorbis_mi355x — C ABI of the MI355X-native batched Vorbis (aoTuV) encode path.
+ *
+ * Drop-in boundary for the per-block encode path of spvkgn/vorbis-aotuv-lancer
+ * (libvorbis 1.3.7 + aoTuV b6.03): vorbis_analysis() -> mapping0_forward() -> {window,
+ * mdct_forward, drft_forward, _vp_* psy, floor1_fit/encode, couple/quantise, residue VQ}
+ * -> vorbis_bitrate_addblock()/flushpacket().  Plain pointers and sizes only; device
+ * pointers are HIP device addresses, `stream` is a hipStream_t passed as void*.
+ *
+ * Every entry point names the reference interface it replaces (file:line relative to
+ * the reference tree).  All functions return 0 on success, a negative VBM_E* otherwise,
+ * and never fall back to a CPU path: without a HIP device they fail with VBM_ENODEV.
+ *
+ * Results are bit-identical to the reference's SCALAR C path (the `#else` branches of
+ * `#ifdef __SSE__`), see DESIGN.md.
+ */
+#ifndef VORBIS_MI355X_H
+#define VORBIS_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VBM_OK       0
+#define VBM_EINVAL  (-131) /* same value as OV_EINVAL, include/vorbis/codec.h:228 */
+#define VBM_EFAULT  (-129) /* OV_EFAULT */
+#define VBM_EIMPL   (-130) /* OV_EIMPL  */
+#define VBM_ENODEV  (-1000)
+#define VBM_EHIP    (-1001)
+
+/* library / device ------------------------------------------------------------------ */
+const char *vbm_version(void);
+/* number of HIP devices visible; <0 on error.  Does not create a context. */
+int vbm_device_count(void);
+/* last HIP error string seen by this library on the calling thread ("" if none) */
+const char *vbm_last_error(void);
+
+/* ---- MDCT ------------------------------------------------------------------------
+ * vbm_mdct_plan replaces mdct_lookup (lib/mdct.h:55-73) + mdct_init (lib/mdct.c:54-92):
+ * trig tables are computed on the host with libm in double and rounded to float exactly
+ * as lib/mdct.c:67-76 does, then kept device-resident.  It also carries the two
+ * rising half-windows the block size can meet (lib/window.c:29-2122; b->window[W],
+ * lib/block.c:218-219) so that windowing fuses into the transform.
+ *
+ *   n        transform size: 2048 (long) or 256 (short) in this release
+ *   short_n  size of the short block of the same mode pair (for n==2048: 256); the
+ *            left/right window halves of a long block next to a short one use it
+ *   win_n / win_short: host pointers to the rising half-windows (n/2 and short_n/2
+ *            floats); may be NULL if only vbm_mdct_forward_batch() will be used.
+ */
+typedef struct vbm_mdct_plan vbm_mdct_plan;
+
+int vbm_mdct_plan_create(vbm_mdct_plan **plan, int n, int short_n,
+                         const float *win_n, const float *win_short);
+void vbm_mdct_plan_destroy(vbm_mdct_plan *plan);
+/* host copy of the trig table (n + n/4 floats) — for parity tests */
+const float *vbm_mdct_plan_trig(const vbm_mdct_plan *plan);
+
+/* Batched mdct_forward(mdct_lookup*, float *in, float *out) — lib/mdct.c:1799 / lib/mdct.h:78.
+ *   d_in : nblocks x n   floats, block-major, device
+ *   d_out: nblocks x n/2 floats, device
+ */
+int vbm_mdct_forward_batch(const vbm_mdct_plan *plan, const float *d_in, float *d_out,
+                           long nblocks, void *stream);
+
+/* Batched _vorbis_apply_window(pcm, winno, blocksizes, lW, W, nW) + mdct_forward —
+ * lib/window.c:2137 + lib/mdct.c:1799 as called from mapping0_forward, lib/mapping0.c:825-843.
+ *   d_pcm    : nblocks x n floats (un-windowed block PCM, block-major)
+ *   d_wflags : one byte per block, bit0 = lW, bit1 = nW (vb->lW / vb->nW; only read for
+ *              long blocks; NULL means every neighbour is long).  Short blocks always
+ *              use the full short window (lib/window.c:2139-2140).
+ */
+int vbm_window_mdct_batch(const vbm_mdct_plan *plan, const float *d_pcm, float *d_out,
+                          const uint8_t *d_wflags, long nblocks, void *stream);
+
+/* Bench helper: time `iters` back-to-back launches of vbm_window_mdct_batch with HIP
+ * events recorded on `stream` (the stream the kernel runs on).  *ms_total receives the
+ * elapsed milliseconds for all iters. */
+int vbm_window_mdct_time(const vbm_mdct_plan *plan, const float *d_pcm, float *d_out,
+                         const uint8_t *d_wflags, long nblocks, int iters, void *stream,
+                         float *ms_total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VORBIS_MI355X_H */

@@ -1,0 +1,48 @@
+"""ctypes binding of libvorbis_mi355x.so (C ABI: include/vorbis_mi355x.h)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvorbis_mi355x.so")
+
+
+class VbmError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise VbmError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the encode path.")
+    return C.CDLL(LIB_PATH)
+
+
+lib = _load()
+
+_c_float_p = C.POINTER(C.c_float)
+
+# name -> (restype, argtypes); must list every symbol include/vorbis_mi355x.h declares
+SIGNATURES = {
+    "vbm_version": (C.c_char_p, []),
+    "vbm_device_count": (C.c_int, []),
+    "vbm_last_error": (C.c_char_p, []),
+    "vbm_mdct_plan_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "vbm_mdct_plan_destroy": (None, [C.c_void_p]),
+    "vbm_mdct_plan_trig": (_c_float_p, [C.c_void_p]),
+    "vbm_mdct_forward_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]),
+    "vbm_window_mdct_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]),
+    "vbm_window_mdct_time": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int,
+                                       C.c_void_p, C.POINTER(C.c_float)]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _f = getattr(lib, _name)
+    _f.restype = _res
+    _f.argtypes = _args
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib.vbm_last_error().decode()
+        raise VbmError(f"{what} failed with code {rc}" + (f": {msg}" if msg else ""))
