@@ -1,0 +1,345 @@
+/* ORACLE — test infrastructure only.
+ *
+ * Per-stream state machine of the encoder, restating
+ *   vorbis_analysis_init      lib/block.c:306-331 (+ _vds_shared_init :181-303 storage part)
+ *   vorbis_block_init         lib/block.c:84-107
+ *   vorbis_analysis_buffer    lib/block.c:411-436
+ *   _preextrapolate_helper    lib/block.c:438-477
+ *   vorbis_analysis_wrote     lib/block.c:482-553
+ *   vorbis_analysis_blockout  lib/block.c:557-812
+ *   _vp_ampmax_decay          lib/psy.c:4504-4515
+ *   vorbis_analysis           lib/analysis.c:29-63
+ *   vorbis_bitrate_addblock / flushpacket (VBR: pass-through)  lib/bitrate.c:88-96, 229-252
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include "oracle.h"
+#include "orc_internal.h"
+
+orc_stream *orc_stream_new(const orc_setup *s)
+{
+    orc_stream *v = (orc_stream *)calloc(1, sizeof(*v));
+    int i;
+    v->s = s;
+    v->pcm_storage = (int)s->blocksizes[1];
+    for (i = 0; i < s->channels; i++) v->pcm[i] = (float *)calloc(v->pcm_storage, sizeof(float));
+    v->lW = 0;
+    v->W = 0;
+    v->centerW = s->blocksizes[1] / 2;
+    v->pcm_current = (int)v->centerW;
+    v->g_ampmax = -9999.;
+    v->mblock = (float *)calloc(2048 * s->channels, sizeof(float));
+    v->tblock = (float *)calloc(256 * s->channels, sizeof(float));
+    v->lownoise_compand_level = (float *)calloc(s->channels, sizeof(float));
+    v->impadnum = 0;
+    /* _ve_envelope_init: storage 128, cursor = blocksizes[1]/2, everything else zero */
+    v->ve_filter = (orc_ve_filter *)calloc(ORC_VE_BANDS * s->channels, sizeof(orc_ve_filter));
+    v->ve_storage = 128;
+    v->ve_mark = (int *)calloc(v->ve_storage, sizeof(int));
+    v->ve_cursor = s->blocksizes[1] / 2;
+    v->sequence = 3;
+    return v;
+}
+
+void orc_stream_free(orc_stream *v)
+{
+    int i;
+    if (!v) return;
+    for (i = 0; i < v->s->channels; i++) free(v->pcm[i]);
+    free(v->mblock); free(v->tblock); free(v->lownoise_compand_level);
+    free(v->ve_filter); free(v->ve_mark);
+    free(v);
+}
+
+orc_block *orc_block_new(const orc_setup *s)
+{
+    orc_block *b = (orc_block *)calloc(1, sizeof(*b));
+    int i, n = (int)s->blocksizes[1];
+    b->ampmax = -9999;
+    for (i = 0; i < s->channels; i++) {
+        b->pcmbuf[i] = (float *)calloc(n, sizeof(float));
+        b->cap_windowed[i] = (float *)calloc(n, sizeof(float));
+        b->cap_gmdct_raw[i] = (float *)calloc(n / 2, sizeof(float));
+        b->cap_gmdct[i] = (float *)calloc(n / 2, sizeof(float));
+        b->cap_logfft[i] = (float *)calloc(n / 2, sizeof(float));
+        b->cap_logmdct[i] = (float *)calloc(n / 2, sizeof(float));
+        b->cap_noise[i] = (float *)calloc(n / 2, sizeof(float));
+        b->cap_tone[i] = (float *)calloc(n / 2, sizeof(float));
+        b->cap_logmask[i] = (float *)calloc(n / 2, sizeof(float));
+        b->cap_epeak[i] = (float *)calloc(n / 2, sizeof(float));
+        b->cap_npeak[i] = (float *)calloc(n / 2, sizeof(float));
+        b->cap_ilogmask[i] = (int *)calloc(n / 2, sizeof(int));
+        b->cap_residue[i] = (int *)calloc(n / 2, sizeof(int));
+    }
+    orc_bits_init(&b->opb);
+    return b;
+}
+
+void orc_block_free(orc_block *b)
+{
+    int i;
+    if (!b) return;
+    for (i = 0; i < ORC_MAXCH; i++) {
+        free(b->pcmbuf[i]); free(b->cap_windowed[i]); free(b->cap_gmdct_raw[i]); free(b->cap_gmdct[i]);
+        free(b->cap_logfft[i]); free(b->cap_logmdct[i]); free(b->cap_noise[i]); free(b->cap_tone[i]);
+        free(b->cap_logmask[i]); free(b->cap_epeak[i]); free(b->cap_npeak[i]); free(b->cap_ilogmask[i]);
+        free(b->cap_residue[i]);
+    }
+    orc_bits_clear(&b->opb);
+    free(b);
+}
+
+float **orc_analysis_buffer(orc_stream *v, int vals, float **ret)
+{
+    int i;
+    const orc_setup *s = v->s;
+    if (v->pcm_current + vals >= v->pcm_storage) {
+        v->pcm_storage = v->pcm_current + vals * 2;
+        for (i = 0; i < s->channels; i++)
+            v->pcm[i] = (float *)realloc(v->pcm[i], v->pcm_storage * sizeof(float));
+    }
+    for (i = 0; i < s->channels; i++) ret[i] = v->pcm[i] + v->pcm_current;
+    return ret;
+}
+
+static void preextrapolate(orc_stream *v)
+{
+    int i;
+    int order = 16;
+    float lpc[16];
+    float *work = (float *)malloc(v->pcm_current * sizeof(*work));
+    long j;
+    v->preextrapolate = 1;
+
+    if (v->pcm_current - v->centerW > order * 2) {
+        for (i = 0; i < v->s->channels; i++) {
+            for (j = 0; j < v->pcm_current; j++) work[j] = v->pcm[i][v->pcm_current - j - 1];
+
+            orc_lpc_from_data(work, lpc, v->pcm_current - v->centerW, order);
+            orc_lpc_predict(lpc, work + v->pcm_current - v->centerW - order, order,
+                            work + v->pcm_current - v->centerW, v->centerW);
+
+            for (j = 0; j < v->pcm_current; j++) v->pcm[i][v->pcm_current - j - 1] = work[j];
+        }
+    }
+    free(work);
+}
+
+int orc_analysis_wrote(orc_stream *v, int vals)
+{
+    const orc_setup *s = v->s;
+    {
+        int i, j;
+        for (i = 0; i < vals; i++)
+            for (j = 0; j < s->channels; j++) v->pcm[j][v->pcm_current + i] *= s->pre_amplitude;
+    }
+
+    if (vals <= 0) {
+        int order = 32;
+        int i;
+        float lpc[32];
+        float *dummy[ORC_MAXCH];
+
+        if (!v->preextrapolate) preextrapolate(v);
+
+        orc_analysis_buffer(v, (int)s->blocksizes[1] * 3, dummy);
+        v->eofflag = v->pcm_current;
+        v->pcm_current += s->blocksizes[1] * 3;
+
+        for (i = 0; i < s->channels; i++) {
+            if (v->eofflag > order * 2) {
+                long n;
+                n = v->eofflag;
+                if (n > s->blocksizes[1]) n = s->blocksizes[1];
+                orc_lpc_from_data(v->pcm[i] + v->eofflag - n, lpc, n, order);
+                orc_lpc_predict(lpc, v->pcm[i] + v->eofflag - order, order, v->pcm[i] + v->eofflag,
+                                v->pcm_current - v->eofflag);
+            } else {
+                memset(v->pcm[i] + v->eofflag, 0, (v->pcm_current - v->eofflag) * sizeof(*v->pcm[i]));
+            }
+        }
+    } else {
+        if (v->pcm_current + vals > v->pcm_storage) return (-131);
+
+        v->pcm_current += vals;
+
+        if (!v->preextrapolate && v->pcm_current - v->centerW > s->blocksizes[1]) preextrapolate(v);
+    }
+    return (0);
+}
+
+static float ampmax_decay(float amp, const orc_stream *v)
+{
+    const orc_setup *s = v->s;
+    int n = s->blocksizes[v->W] / 2;
+    float secs = (float)n / s->rate;
+
+    amp += secs * s->psy_g.ampmax_att_per_sec;
+    if (amp < -9999) amp = -9999;
+    return (amp);
+}
+
+int orc_analysis_blockout(orc_stream *v, orc_block *vb)
+{
+    int i;
+    const orc_setup *s = v->s;
+    long beginW = v->centerW - s->blocksizes[v->W] / 2, centerNext;
+
+    if (!v->preextrapolate) return (0);
+    if (v->eofflag == -1) return (0);
+
+    {
+        long bp = orc_ve_envelope_search(v);
+        if (bp == -1) {
+            if (v->eofflag == 0) return (0);
+            v->nW = 0;
+        } else {
+            if (s->blocksizes[0] == s->blocksizes[1]) v->nW = 0;
+            else v->nW = bp;
+        }
+    }
+
+    centerNext = v->centerW + s->blocksizes[v->W] / 4 + s->blocksizes[v->nW] / 4;
+
+    {
+        long blockbound = centerNext + s->blocksizes[v->nW] / 2;
+        if (v->pcm_current < blockbound) return (0);
+    }
+
+    vb->lW = v->lW;
+    vb->W = v->W;
+    vb->nW = v->nW;
+
+    if (v->W) {
+        if (!v->lW || !v->nW) vb->blocktype = 0; /* BLOCKTYPE_TRANSITION */
+        else vb->blocktype = 1;                  /* BLOCKTYPE_LONG */
+    } else {
+        if (orc_ve_envelope_mark(v)) vb->blocktype = 0; /* BLOCKTYPE_IMPULSE */
+        else vb->blocktype = 1;                         /* BLOCKTYPE_PADDING */
+    }
+
+    vb->sequence = v->sequence++;
+    vb->granulepos = v->granulepos;
+    vb->pcmend = s->blocksizes[v->W];
+    vb->eofflag = 0;
+
+    if (vb->ampmax > v->g_ampmax) v->g_ampmax = vb->ampmax;
+    v->g_ampmax = ampmax_decay(v->g_ampmax, v);
+    vb->ampmax = v->g_ampmax;
+
+    for (i = 0; i < s->channels; i++)
+        memcpy(vb->pcmbuf[i], v->pcm[i] + beginW, vb->pcmend * sizeof(float));
+
+    if (v->eofflag) {
+        if (v->centerW >= v->eofflag) {
+            v->eofflag = -1;
+            vb->eofflag = 1;
+            return (1);
+        }
+    }
+
+    {
+        int new_centerNext = s->blocksizes[1] / 2;
+        int movementW = centerNext - new_centerNext;
+
+        if (movementW > 0) {
+            orc_ve_envelope_shift(v, movementW);
+            v->pcm_current -= movementW;
+
+            for (i = 0; i < s->channels; i++)
+                memmove(v->pcm[i], v->pcm[i] + movementW, v->pcm_current * sizeof(*v->pcm[i]));
+
+            v->lW = v->W;
+            v->W = v->nW;
+            v->centerW = new_centerNext;
+
+            if (v->eofflag) {
+                v->eofflag -= movementW;
+                if (v->eofflag <= 0) v->eofflag = -1;
+                if (v->centerW >= v->eofflag) {
+                    v->granulepos += movementW - (v->centerW - v->eofflag);
+                } else {
+                    v->granulepos += movementW;
+                }
+            } else {
+                v->granulepos += movementW;
+            }
+        }
+    }
+    return (1);
+}
+
+int orc_analysis(orc_stream *v, orc_block *vb)
+{
+    orc_bits_reset(&vb->opb);
+    return orc_mapping0_forward(v, vb);
+}
+
+const unsigned char *orc_block_packet(const orc_block *vb, long *bytes)
+{
+    *bytes = orc_bits_bytes(&vb->opb);
+    return vb->opb.buf;
+}
+
+/* ---- survey probe: signal + driver of SURVEY.md Appendix B ----------------------------- */
+static unsigned probe_lcg;
+static float probe_rnd(void)
+{
+    probe_lcg = probe_lcg * 1664525u + 1013904223u;
+    return ((probe_lcg >> 8) & 0xffff) / 32768.f - 1.f;
+}
+
+long orc_encode_probe(const orc_setup *s, int secs, const char *out_path, double *seconds_spent)
+{
+    orc_stream *v = orc_stream_new(s);
+    orc_block *vb = orc_block_new(s);
+    FILE *f = out_path ? fopen(out_path, "wb") : NULL;
+    long rate = s->rate, total = rate * secs, pos = 0, npk = 0;
+    int ch = s->channels, i, c;
+    struct timespec t0, t1;
+    float *b[ORC_MAXCH];
+    probe_lcg = 12345u;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    while (1) {
+        if (pos >= total) {
+            orc_analysis_wrote(v, 0);
+        } else {
+            int n = 1024;
+            orc_analysis_buffer(v, 1024, b);
+            for (i = 0; i < n; i++) {
+                double t = (double)(pos + i) / rate;
+                int burst = (((pos + i) / (rate / 3)) % 4 == 3) && ((pos + i) % (rate / 3)) < 200;
+                for (c = 0; c < ch; c++) {
+                    float smp = 0.3f * sin(2 * M_PI * 440.0 * (c + 1) * t) + 0.2f * sin(2 * M_PI * 3000.0 * t + c) +
+                                0.05f * probe_rnd();
+                    if (burst) smp += 0.6f * probe_rnd();
+                    b[c][i] = smp;
+                }
+            }
+            orc_analysis_wrote(v, n);
+            pos += n;
+        }
+        while (orc_analysis_blockout(v, vb) == 1) {
+            long bytes;
+            const unsigned char *pkt;
+            orc_analysis(v, vb);
+            pkt = orc_block_packet(vb, &bytes);
+            if (f) {
+                int len = (int)bytes;
+                fwrite(&len, 4, 1, f);
+                fwrite(pkt, 1, bytes, f);
+            }
+            npk++;
+        }
+        if (pos >= total) break;
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (seconds_spent) *seconds_spent = (t1.tv_sec - t0.tv_sec) + (t1.tv_nsec - t0.tv_nsec) * 1e-9;
+    if (f) fclose(f);
+    orc_block_free(vb);
+    orc_stream_free(v);
+    return npk;
+}

@@ -52,3 +52,33 @@ class Oracle:
             self.lib.orc_apply_window(_p(flat[i]), C.c_long(n), _p(win_l), C.c_long(2 * len(win_l)),
                                       _p(win_r), C.c_long(2 * len(win_r)))
         return x
+
+
+# ---- full encoder ---------------------------------------------------------------------
+import os as _os
+
+_DATA = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))),
+                      "vorbis_aotuv_lancer_amd", "data")
+
+
+class Setup:
+    """orc_setup for one (channels, rate, quality) class, from the committed mode pack."""
+
+    def __init__(self, oracle, ch, rate, q):
+        self.o = oracle
+        lib = oracle.lib
+        lib.orc_setup_load.restype = C.c_void_p
+        lib.orc_setup_load.argtypes = [C.c_char_p, C.c_char_p]
+        lib.orc_encode_probe.restype = C.c_long
+        lib.orc_encode_probe.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.POINTER(C.c_double)]
+        mode = _os.path.join(_DATA, f"mode_{ch}ch_{rate}_q{q:g}.vpk")
+        self.h = lib.orc_setup_load(_os.path.join(_DATA, "common.vpk").encode(), mode.encode())
+        if not self.h:
+            raise RuntimeError(f"cannot load {mode}")
+        self.ch, self.rate, self.q = ch, rate, q
+
+    def encode_probe(self, secs, out_path=None):
+        """SURVEY.md Appendix B signal + driver; returns (packets, seconds)."""
+        t = C.c_double()
+        n = self.o.lib.orc_encode_probe(self.h, secs, out_path.encode() if out_path else None, C.byref(t))
+        return n, t.value
