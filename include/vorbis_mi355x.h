@@ -74,6 +74,27 @@ int vbm_mdct_forward_batch(const vbm_mdct_plan *plan, const float *d_in, float *
 int vbm_window_mdct_batch(const vbm_mdct_plan *plan, const float *d_pcm, float *d_out,
                           const uint8_t *d_wflags, long nblocks, void *stream);
 
+/* Batched tonal-estimation transform of mapping0_forward loop A (lib/mapping0.c:825-888):
+ * _vorbis_apply_window + drft_forward (lib/smallft.c:6770, FFTPACK scalar path) + the
+ * log-power conversion
+ *     logfft[0] = scale_dB + todB(re0) + .345 ;  logfft[k] = scale_dB + .5f*todB(re_k^2+im_k^2) + .345
+ * and the per-block maximum local_ampmax = min(0, max_k logfft[k]) (:862-888).
+ *   d_pcm          : nblocks x n floats (un-windowed)
+ *   d_logfft       : nblocks x n/2 floats
+ *   d_local_ampmax : nblocks floats
+ */
+int vbm_window_fft_log_batch(const vbm_mdct_plan *plan, const float *d_pcm, float *d_logfft,
+                             float *d_local_ampmax, const uint8_t *d_wflags, long nblocks, void *stream);
+/* host copy of the FFTPACK twiddle table (n floats = drft_lookup.trigcache + n) — for parity tests */
+const float *vbm_mdct_plan_fft_twiddles(const vbm_mdct_plan *plan);
+
+/* Host-only table builders (no device needed): the lookup tables the plans upload, for
+ * integrators and for CPU-side parity checks.
+ *   vbm_host_mdct_trig     n + n/4 floats  (mdct_init, lib/mdct.c:67-76)
+ *   vbm_host_fft_twiddles  n floats        (drfti1,   lib/smallft.c:5576-5644; = trigcache + n) */
+int vbm_host_mdct_trig(int n, float *out);
+int vbm_host_fft_twiddles(int n, float *out);
+
 /* Bench helper: time `iters` back-to-back launches of vbm_window_mdct_batch with HIP
  * events recorded on `stream` (the stream the kernel runs on).  *ms_total receives the
  * elapsed milliseconds for all iters. */

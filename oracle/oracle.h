@@ -81,6 +81,7 @@ typedef struct {
 void orc_drft_init(orc_drft *l, int n);
 void orc_drft_clear(orc_drft *l);
 void orc_drft_forward(const orc_drft *l, float *data);
+float orc_fft_logpower(const orc_drft *fft, float *pcm, int n); /* lib/mapping0.c:795, 847-888 */
 
 /* ---- window (lib/window.c:2137-2261) ------------------------------------------------- */
 void orc_apply_window(float *d, long n, const float *win_l, long ln, const float *win_r, long rn);

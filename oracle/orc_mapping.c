@@ -15,6 +15,27 @@
 #include "oracle.h"
 #include "orc_internal.h"
 
+/* lib/mapping0.c:795, 847-888: FFT in place, log-power spectrum into pcm[0..n/2), returns the
+ * block's local_ampmax (already clamped to <= 0) */
+float orc_fft_logpower(const orc_drft *fft, float *pcm, int n)
+{
+    float scale = 4.f / n;
+    float scale_dB = orc_todB(&scale) + .345;
+    float *logfft = pcm;
+    float local_ampmax;
+    int j;
+    orc_drft_forward(fft, pcm);
+    logfft[0] = scale_dB + orc_todB(pcm) + .345;
+    local_ampmax = logfft[0];
+    for (j = 1; j < n - 1; j += 2) {
+        float temp = pcm[j] * pcm[j] + pcm[j + 1] * pcm[j + 1];
+        temp = logfft[(j + 1) >> 1] = scale_dB + .5f * orc_todB(&temp) + .345;
+        if (temp > local_ampmax) local_ampmax = temp;
+    }
+    if (local_ampmax > 0.f) local_ampmax = 0.f;
+    return local_ampmax;
+}
+
 int orc_mapping0_forward(orc_stream *v, orc_block *vb)
 {
     const orc_setup *s = v->s;
@@ -63,8 +84,6 @@ int orc_mapping0_forward(orc_stream *v, orc_block *vb)
     }
 
     for (i = 0; i < ch; i++) {
-        float scale = 4.f / n;
-        float scale_dB;
         float *pcm = vb->pcmbuf[i];
         float *logfft = pcm;
 
@@ -72,8 +91,6 @@ int orc_mapping0_forward(orc_stream *v, orc_block *vb)
         gmdct[i] = (float *)malloc(n / 2 * sizeof(float));
         epeak[i] = (float *)malloc(n / 2 * sizeof(float));
         npeak[i] = (float *)malloc((n / 2 / partition + 1) * sizeof(float));
-
-        scale_dB = orc_todB(&scale) + .345;
 
         poste[i] = orc_postnoise_detection(pcm, n, block_mode, v->lW_block_mode);
 
@@ -83,16 +100,7 @@ int orc_mapping0_forward(orc_stream *v, orc_block *vb)
         orc_mdct_forward(&s->mdct[vb->W], pcm, gmdct[i]);
         if (v->capture) memcpy(vb->cap_gmdct_raw[i], gmdct[i], n / 2 * sizeof(float));
 
-        orc_drft_forward(&s->fft[vb->W], pcm);
-        logfft[0] = scale_dB + orc_todB(pcm) + .345;
-        local_ampmax[i] = logfft[0];
-        for (j = 1; j < n - 1; j += 2) {
-            float temp = pcm[j] * pcm[j] + pcm[j + 1] * pcm[j + 1];
-            temp = logfft[(j + 1) >> 1] = scale_dB + .5f * orc_todB(&temp) + .345;
-            if (temp > local_ampmax[i]) local_ampmax[i] = temp;
-        }
-
-        if (local_ampmax[i] > 0.f) local_ampmax[i] = 0.f;
+        local_ampmax[i] = orc_fft_logpower(&s->fft[vb->W], pcm, n);
         if (local_ampmax[i] > global_ampmax) global_ampmax = local_ampmax[i];
         if (v->capture) memcpy(vb->cap_logfft[i], logfft, n / 2 * sizeof(float));
     }

@@ -82,3 +82,34 @@ class Setup:
         t = C.c_double()
         n = self.o.lib.orc_encode_probe(self.h, secs, out_path.encode() if out_path else None, C.byref(t))
         return n, t.value
+
+
+class _Drft(C.Structure):
+    _fields_ = [("n", C.c_int), ("trigcache", C.POINTER(C.c_float)), ("splitcache", C.POINTER(C.c_int))]
+
+
+def _drft(oracle, n):
+    cache = oracle.__dict__.setdefault("_drft", {})
+    if n not in cache:
+        d = _Drft()
+        oracle.lib.orc_drft_init(C.byref(d), n)
+        cache[n] = d
+    return cache[n]
+
+
+def fft_twiddles(oracle, n):
+    d = _drft(oracle, n)
+    return np.ctypeslib.as_array(d.trigcache, shape=(3 * n,))[n:2 * n].copy()
+
+
+def fft_logpower(oracle, windowed):
+    """windowed: (..., n) float32 -> (logfft (..., n/2), local_ampmax (...))  [lib/mapping0.c:847-888]"""
+    x = np.array(windowed, dtype=np.float32, copy=True)
+    n = x.shape[-1]
+    d = _drft(oracle, n)
+    oracle.lib.orc_fft_logpower.restype = C.c_float
+    flat = x.reshape(-1, n)
+    amp = np.empty(flat.shape[0], np.float32)
+    for i in range(flat.shape[0]):
+        amp[i] = oracle.lib.orc_fft_logpower(C.byref(d), _p(flat[i]), n)
+    return flat[:, :n // 2].reshape(x.shape[:-1] + (n // 2,)).copy(), amp.reshape(x.shape[:-1])

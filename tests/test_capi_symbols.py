@@ -46,3 +46,17 @@ def test_product_never_imports_oracle():
                 if re.search(r"liboracle|oracle/|import\s+orc\b|from\s+tests", t):
                     bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_host_tables_match_oracle(oracle):
+    """mdct trig and FFTPACK twiddles built by the product's host code == oracle's (bit-exact)."""
+    import numpy as np
+    import vorbis_aotuv_lancer_amd as v
+    from tests import orc
+    for n in (256, 2048):
+        a = np.zeros(n, np.float32)
+        assert v.lib.vbm_host_fft_twiddles(n, a.ctypes.data) == 0
+        assert np.array_equal(a.view(np.uint32), orc.fft_twiddles(oracle, n).view(np.uint32))
+        t = np.zeros(n + n // 4, np.float32)
+        assert v.lib.vbm_host_mdct_trig(n, t.ctypes.data) == 0
+        assert np.array_equal(t.view(np.uint32), oracle.mdct_trig(n).view(np.uint32))

@@ -5,7 +5,7 @@ Runs only in the authoring container (needs /root/reference as TEXT; nothing fro
 reference is compiled, imported or executed).  Outputs are committed under
 vorbis_aotuv_lancer_amd/data/ because the GPU box has no /root/reference.
 
-    python tools/extract_tables.py windows     -> data/windows.vpk   (lib/window.c:29-2122)
+    python tools/extract_tables.py common   -> data/common.vpk  (windows lib/window.c:29-2122, psy/floor tables)
 
 Why the windows cannot be recomputed: the literals in lib/window.c were printed with 10
 decimals, so e.g. vwin2048[0] = 0.0000009241F is NOT round(sin(pi/2 sin^2(...))) — the
@@ -76,7 +76,7 @@ def extract_common():
     print("wrote common.vpk:", {k: v.shape for k, v in arrays.items()})
 
 
-STEPS = {"windows": extract_windows, "common": extract_common}
+STEPS = {"common": extract_common}
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(STEPS)

@@ -8,7 +8,7 @@ call raises if the HIP library or a GPU is missing.
 """
 from ._lib import lib, LIB_PATH, VbmError, check  # noqa: F401
 from .tables import window_table  # noqa: F401
-from .mdct import MdctLookup, mdct_forward, window_mdct  # noqa: F401
+from .mdct import MdctLookup, mdct_forward, window_mdct, window_fft_log  # noqa: F401
 
 __all__ = ["lib", "LIB_PATH", "VbmError", "check", "window_table",
-           "MdctLookup", "mdct_forward", "window_mdct"]
+           "MdctLookup", "mdct_forward", "window_mdct", "window_fft_log"]

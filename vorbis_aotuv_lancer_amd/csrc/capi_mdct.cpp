@@ -36,7 +36,9 @@ struct vbm_mdct_plan {
     int short_n;
     int has_window;
     std::vector<float> trig;   // host copy, n + n/4
+    std::vector<float> fftwa;  // FFTPACK twiddles, n floats
     float *d_trig;
+    float *d_fftwa;
     float *d_win_n;
     float *d_win_short;
 };
@@ -58,6 +60,66 @@ static void build_trig(std::vector<float> &T, int n)
     }
 }
 
+// Twiddles of drfti1 (reference lib/smallft.c:5576-5644): factor n with trial order {4,2,3,5},
+// move a factor 2 to the front, then for every factor but the last store cos/sin(fi*argld)
+// with arg formed in float and libm evaluated in double.
+static void build_fft_twiddles(std::vector<float> &wa, int n)
+{
+    wa.assign(n, 0.f);
+    std::vector<int> fac;
+    {
+        static const int tries[4] = {4, 2, 3, 5};
+        int nl = n, j = 0, ntry = 0;
+        while (nl != 1) {
+            ntry = (j < 4) ? tries[j] : ntry + 2;
+            j++;
+            while (nl % ntry == 0) {
+                nl /= ntry;
+                if (ntry == 2 && !fac.empty()) fac.insert(fac.begin(), 2);
+                else fac.push_back(ntry);
+            }
+        }
+    }
+    const float tpi = 6.28318530717958648f;
+    const float argh = tpi / n;
+    int is = 0, l1 = 1;
+    for (size_t k1 = 0; k1 + 1 < fac.size(); k1++) {
+        int ip = fac[k1], ld = 0, l2 = l1 * ip, ido = n / l2;
+        for (int j = 0; j < ip - 1; j++) {
+            ld += l1;
+            int i = is;
+            float argld = (float)ld * argh;
+            float fi = 0.f;
+            for (int ii = 2; ii < ido; ii += 2) {
+                fi += 1.f;
+                float arg = fi * argld;
+                wa[i++] = (float)cos((double)arg);   // C semantics: double libm on a float argument
+                wa[i++] = (float)sin((double)arg);   // (C++ would otherwise pick the float overload)
+            }
+            is += ido;
+        }
+        l1 = l2;
+    }
+}
+
+extern "C" int vbm_host_mdct_trig(int n, float *out)
+{
+    if (!out || n < 64 || (n & (n - 1))) return VBM_EINVAL;
+    std::vector<float> t;
+    build_trig(t, n);
+    memcpy(out, t.data(), t.size() * sizeof(float));
+    return VBM_OK;
+}
+
+extern "C" int vbm_host_fft_twiddles(int n, float *out)
+{
+    if (!out || n < 4 || (n & (n - 1))) return VBM_EINVAL;
+    std::vector<float> t;
+    build_fft_twiddles(t, n);
+    memcpy(out, t.data(), t.size() * sizeof(float));
+    return VBM_OK;
+}
+
 extern "C" int vbm_mdct_plan_create(vbm_mdct_plan **out, int n, int short_n,
                                     const float *win_n, const float *win_short)
 {
@@ -75,12 +137,15 @@ extern "C" int vbm_mdct_plan_create(vbm_mdct_plan **out, int n, int short_n,
     p->n = n;
     p->short_n = (n == 2048) ? short_n : n;
     p->has_window = win_n != nullptr;
-    p->d_trig = p->d_win_n = p->d_win_short = nullptr;
+    p->d_trig = p->d_win_n = p->d_win_short = p->d_fftwa = nullptr;
     build_trig(p->trig, n);
+    build_fft_twiddles(p->fftwa, n);
     hipError_t e;
 #define CK(x) do { e = (x); if (e != hipSuccess) { int rc = vbm_set_hip_error(e, #x); vbm_mdct_plan_destroy(p); return rc; } } while (0)
     CK(hipMalloc((void **)&p->d_trig, p->trig.size() * sizeof(float)));
     CK(hipMemcpy(p->d_trig, p->trig.data(), p->trig.size() * sizeof(float), hipMemcpyHostToDevice));
+    CK(hipMalloc((void **)&p->d_fftwa, p->fftwa.size() * sizeof(float)));
+    CK(hipMemcpy(p->d_fftwa, p->fftwa.data(), p->fftwa.size() * sizeof(float), hipMemcpyHostToDevice));
     if (win_n) {
         CK(hipMalloc((void **)&p->d_win_n, (n / 2) * sizeof(float)));
         CK(hipMemcpy(p->d_win_n, win_n, (n / 2) * sizeof(float), hipMemcpyHostToDevice));
@@ -98,12 +163,14 @@ extern "C" void vbm_mdct_plan_destroy(vbm_mdct_plan *p)
 {
     if (!p) return;
     if (p->d_trig) (void)hipFree(p->d_trig);
+    if (p->d_fftwa) (void)hipFree(p->d_fftwa);
     if (p->d_win_n) (void)hipFree(p->d_win_n);
     if (p->d_win_short) (void)hipFree(p->d_win_short);
     delete p;
 }
 
 extern "C" const float *vbm_mdct_plan_trig(const vbm_mdct_plan *p) { return p ? p->trig.data() : nullptr; }
+extern "C" const float *vbm_mdct_plan_fft_twiddles(const vbm_mdct_plan *p) { return p ? p->fftwa.data() : nullptr; }
 
 static int check_batch_args(const vbm_mdct_plan *p, const void *in, const void *out, long nblocks)
 {
@@ -131,6 +198,18 @@ extern "C" int vbm_window_mdct_batch(const vbm_mdct_plan *p, const float *d_pcm,
     if (!p->has_window) return VBM_EINVAL;
     rc = vbm_launch_window_mdct(d_pcm, d_out, d_wflags, p->d_trig, p->d_win_n, p->d_win_short, p->n,
                                 p->short_n, 1, nblocks, 0, (hipStream_t)stream);
+    return rc ? VBM_EHIP : VBM_OK;
+}
+
+extern "C" int vbm_window_fft_log_batch(const vbm_mdct_plan *p, const float *d_pcm, float *d_logfft,
+                                        float *d_local_ampmax, const uint8_t *d_wflags, long nblocks,
+                                        void *stream)
+{
+    int rc = check_batch_args(p, d_pcm, d_logfft, nblocks);
+    if (rc) return rc;
+    if (!p->has_window || (nblocks > 0 && !d_local_ampmax)) return VBM_EINVAL;
+    rc = vbm_launch_window_fft_log(d_pcm, d_logfft, d_local_ampmax, d_wflags, p->d_fftwa, p->d_win_n,
+                                   p->d_win_short, p->n, p->short_n, nblocks, (hipStream_t)stream);
     return rc ? VBM_EHIP : VBM_OK;
 }
 

@@ -1,0 +1,285 @@
+// Window + real FFT + log-power spectrum for gfx950, one wavefront per block.
+//
+// Replaces, for a batch of blocks, the tonal-estimation half of mapping0_forward loop A
+// (reference lib/mapping0.c:825-888): _vorbis_apply_window, drft_forward (FFTPACK radix 4/2,
+// lib/smallft.c:5652-5807, 6111-6170), then
+//     logfft[0]        = scale_dB + todB(re0)            + .345
+//     logfft[(j+1)>>1] = scale_dB + .5f*todB(re^2+im^2)  + .345      (j = 1,3,..,n-3)
+//     local_ampmax     = min(0, max logfft)
+// Bit-identical to the scalar reference: the FFTPACK pass structure (factors applied last
+// to first, ping-pong between two buffers) and every butterfly expression are kept; only
+// the schedule changes — each pass's independent butterflies are spread over the 64 lanes,
+// the two ping-pong buffers live in LDS, twiddles (computed on the host with libm exactly
+// as drfti1 does, lib/smallft.c:5629-5640) are LDS-resident.  `+ .345` is a double add
+// rounded to float, as in the C source.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "mdct_kernel.h"
+
+namespace {
+
+constexpr int WAVES_PER_WG = 4;
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// lib/scales.h:43-51
+__device__ __forceinline__ float todB(float x)
+{
+    uint32_t i = __float_as_uint(x) & 0x7fffffffu;
+    return (float)((float)i * 7.17711438e-7f - 764.6161886f);
+}
+
+// ---- FFTPACK forward passes, CC(i,k,j) = cc[i + ido*(k + l1*j)], CH(i,j,k) = ch[i + ido*(j + R*k)]
+template <int IDO, int L1>
+__device__ __forceinline__ void radf4_pass(const float *cc, float *ch, const float *wa1, const float *wa2,
+                                           const float *wa3, int lane)
+{
+#define CC(i, k, j) cc[(i) + IDO * ((k) + L1 * (j))]
+#define CH(i, j, k) ch[(i) + IDO * ((j) + 4 * (k))]
+    for (int k = lane; k < L1; k += 64) {
+        float tr1 = CC(0, k, 1) + CC(0, k, 3);
+        float tr2 = CC(0, k, 0) + CC(0, k, 2);
+        CH(0, 0, k) = tr1 + tr2;
+        CH(IDO - 1, 3, k) = tr2 - tr1;
+        CH(IDO - 1, 1, k) = CC(0, k, 0) - CC(0, k, 2);
+        CH(0, 2, k) = CC(0, k, 3) - CC(0, k, 1);
+    }
+    if (IDO < 2) return;
+    if (IDO > 2) {
+        constexpr int PER_K = IDO / 2 - 1;
+        constexpr int TOTAL = L1 * PER_K;
+        for (int t = lane; t < TOTAL; t += 64) {
+            int k = t / PER_K;
+            int i = 2 + 2 * (t - k * PER_K);
+            int ic = IDO - i;
+            float cr2 = wa1[i - 2] * CC(i - 1, k, 1) + wa1[i - 1] * CC(i, k, 1);
+            float ci2 = wa1[i - 2] * CC(i, k, 1) - wa1[i - 1] * CC(i - 1, k, 1);
+            float cr3 = wa2[i - 2] * CC(i - 1, k, 2) + wa2[i - 1] * CC(i, k, 2);
+            float ci3 = wa2[i - 2] * CC(i, k, 2) - wa2[i - 1] * CC(i - 1, k, 2);
+            float cr4 = wa3[i - 2] * CC(i - 1, k, 3) + wa3[i - 1] * CC(i, k, 3);
+            float ci4 = wa3[i - 2] * CC(i, k, 3) - wa3[i - 1] * CC(i - 1, k, 3);
+            float tr1 = cr2 + cr4, tr4 = cr4 - cr2;
+            float ti1 = ci2 + ci4, ti4 = ci2 - ci4;
+            float ti2 = CC(i, k, 0) + ci3, ti3 = CC(i, k, 0) - ci3;
+            float tr2 = CC(i - 1, k, 0) + cr3, tr3 = CC(i - 1, k, 0) - cr3;
+            CH(i - 1, 0, k) = tr1 + tr2;
+            CH(i, 0, k) = ti1 + ti2;
+            CH(ic - 1, 1, k) = tr3 - ti4;
+            CH(ic, 1, k) = tr4 - ti3;
+            CH(i - 1, 2, k) = ti4 + tr3;
+            CH(i, 2, k) = tr4 + ti3;
+            CH(ic - 1, 3, k) = tr2 - tr1;
+            CH(ic, 3, k) = ti1 - ti2;
+        }
+        if (IDO & 1) return;
+    }
+    constexpr float hsqt2 = .70710678118654752f;
+    for (int k = lane; k < L1; k += 64) {
+        float ti1 = -hsqt2 * (CC(IDO - 1, k, 1) + CC(IDO - 1, k, 3));
+        float tr1 = hsqt2 * (CC(IDO - 1, k, 1) - CC(IDO - 1, k, 3));
+        CH(IDO - 1, 0, k) = tr1 + CC(IDO - 1, k, 0);
+        CH(IDO - 1, 2, k) = CC(IDO - 1, k, 0) - tr1;
+        CH(0, 1, k) = ti1 - CC(IDO - 1, k, 2);
+        CH(0, 3, k) = ti1 + CC(IDO - 1, k, 2);
+    }
+#undef CH
+#undef CC
+}
+
+template <int IDO, int L1>
+__device__ __forceinline__ void radf2_pass(const float *cc, float *ch, const float *wa1, int lane)
+{
+#define CC(i, k, j) cc[(i) + IDO * ((k) + L1 * (j))]
+#define CH(i, j, k) ch[(i) + IDO * ((j) + 2 * (k))]
+    for (int k = lane; k < L1; k += 64) {
+        CH(0, 0, k) = CC(0, k, 0) + CC(0, k, 1);
+        CH(IDO - 1, 1, k) = CC(0, k, 0) - CC(0, k, 1);
+    }
+    if (IDO < 2) return;
+    if (IDO > 2) {
+        constexpr int PER_K = IDO / 2 - 1;
+        constexpr int TOTAL = L1 * PER_K;
+        for (int t = lane; t < TOTAL; t += 64) {
+            int k = t / PER_K;
+            int i = 2 + 2 * (t - k * PER_K);
+            int ic = IDO - i;
+            float tr2 = wa1[i - 2] * CC(i - 1, k, 1) + wa1[i - 1] * CC(i, k, 1);
+            float ti2 = wa1[i - 2] * CC(i, k, 1) - wa1[i - 1] * CC(i - 1, k, 1);
+            CH(i, 0, k) = CC(i, k, 0) + ti2;
+            CH(ic, 1, k) = ti2 - CC(i, k, 0);
+            CH(i - 1, 0, k) = CC(i - 1, k, 0) + tr2;
+            CH(ic - 1, 1, k) = CC(i - 1, k, 0) - tr2;
+        }
+        if (IDO % 2 == 1) return;
+    }
+    for (int k = lane; k < L1; k += 64) {
+        CH(0, 1, k) = -CC(IDO - 1, k, 1);
+        CH(IDO - 1, 0, k) = CC(IDO - 1, k, 0);
+    }
+#undef CH
+#undef CC
+}
+
+// drftf1 (lib/smallft.c:6111-6170) unrolled for the two factorisations in use:
+//   n = 2048: ifac = {2,4,4,4,4,4}  ->  passes (ip,l1,ido) = (4,512,1) (4,128,4) (4,32,16) (4,8,64) (4,2,256) (2,1,1024)
+//   n = 256 : ifac = {4,4,4,4}      ->  passes (4,64,1) (4,16,4) (4,4,16) (4,1,64)
+// wa offsets: iw starts at n and drops by (ip-1)*ido per pass; pointers are wa + iw - 1.
+template <int N>
+__device__ __forceinline__ void fft_forward(float *c, float *ch, const float *wa, int lane);
+
+template <>
+__device__ __forceinline__ void fft_forward<2048>(float *c, float *ch, const float *wa, int lane)
+{
+    // pass 0: ip 4, l1 512, ido 1, iw = 2048-3 = 2045
+    radf4_pass<1, 512>(c, ch, wa + 2044, wa + 2045, wa + 2046, lane);
+    wave_lds_sync();
+    // pass 1: ip 4, l1 128, ido 4, iw = 2045-12 = 2033
+    radf4_pass<4, 128>(ch, c, wa + 2032, wa + 2036, wa + 2040, lane);
+    wave_lds_sync();
+    // pass 2: ip 4, l1 32, ido 16, iw = 2033-48 = 1985
+    radf4_pass<16, 32>(c, ch, wa + 1984, wa + 2000, wa + 2016, lane);
+    wave_lds_sync();
+    // pass 3: ip 4, l1 8, ido 64, iw = 1985-192 = 1793
+    radf4_pass<64, 8>(ch, c, wa + 1792, wa + 1856, wa + 1920, lane);
+    wave_lds_sync();
+    // pass 4: ip 4, l1 2, ido 256, iw = 1793-768 = 1025
+    radf4_pass<256, 2>(c, ch, wa + 1024, wa + 1280, wa + 1536, lane);
+    wave_lds_sync();
+    // pass 5: ip 2, l1 1, ido 1024, iw = 1025-1024 = 1
+    radf2_pass<1024, 1>(ch, c, wa + 0, lane);
+    wave_lds_sync();
+}
+
+template <>
+__device__ __forceinline__ void fft_forward<256>(float *c, float *ch, const float *wa, int lane)
+{
+    // pass 0: l1 64, ido 1, iw = 256-3 = 253
+    radf4_pass<1, 64>(c, ch, wa + 252, wa + 253, wa + 254, lane);
+    wave_lds_sync();
+    // pass 1: l1 16, ido 4, iw = 253-12 = 241
+    radf4_pass<4, 16>(ch, c, wa + 240, wa + 244, wa + 248, lane);
+    wave_lds_sync();
+    // pass 2: l1 4, ido 16, iw = 241-48 = 193
+    radf4_pass<16, 4>(c, ch, wa + 192, wa + 208, wa + 224, lane);
+    wave_lds_sync();
+    // pass 3: l1 1, ido 64, iw = 193-192 = 1
+    radf4_pass<64, 1>(ch, c, wa + 0, wa + 64, wa + 128, lane);
+    wave_lds_sync();
+}
+
+template <int N>
+__global__ __launch_bounds__(64 * WAVES_PER_WG)
+void k_window_fft_log(const float *__restrict__ pcm, float *__restrict__ logfft,
+                      float *__restrict__ local_ampmax, const uint8_t *__restrict__ wflags,
+                      const float *__restrict__ wa_g,      // FFTPACK twiddles, N floats (trigcache + N)
+                      const float *__restrict__ win_self, const float *__restrict__ win_short,
+                      int short_n, long nblocks)
+{
+    __shared__ __attribute__((aligned(16))) float s_wa[N];
+    __shared__ __attribute__((aligned(16))) float s_win[N / 2];
+    __shared__ __attribute__((aligned(16))) float s_wshort[(N == 2048) ? 512 : 4];
+    __shared__ __attribute__((aligned(16))) float s_buf[WAVES_PER_WG][2][N];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    for (int i = tid; i < N; i += blockDim.x) s_wa[i] = wa_g[i];
+    for (int i = tid; i < N / 2; i += blockDim.x) s_win[i] = win_self[i];
+    if (N == 2048)
+        for (int i = tid; i < (short_n >> 1); i += blockDim.x) s_wshort[i] = win_short[i];
+    __syncthreads();
+
+    float *c = s_buf[wave][0];
+    float *ch = s_buf[wave][1];
+    const float scale = 4.f / N;
+    const float scale_dB = (float)((double)todB(scale) + .345);  // lib/mapping0.c:795
+
+    for (long blk = (long)blockIdx.x * WAVES_PER_WG + wave; blk < nblocks; blk += (long)gridDim.x * WAVES_PER_WG) {
+        // ---- load + window (lib/window.c:2137-2258) into LDS ----------------------------
+        int ln = N, rn = N;
+        const float *wl = s_win, *wr = s_win;
+        if (N == 2048 && wflags) {
+            int f = wflags[blk];
+            if (!(f & 1)) { ln = short_n; wl = s_wshort; }
+            if (!(f & 2)) { rn = short_n; wr = s_wshort; }
+        }
+        const float4 *src = reinterpret_cast<const float4 *>(pcm + blk * N);
+#pragma unroll
+        for (int g = 0; g < N / 256; g++) {
+            int q = lane + 64 * g;
+            int i = 4 * q;
+            float4 d = src[q];
+            if (i < N / 2) {
+                int lb = N / 4 - (ln >> 2);
+                if (i < lb) d = make_float4(0.f, 0.f, 0.f, 0.f);
+                else if (i < lb + (ln >> 1)) {
+                    float4 w = *reinterpret_cast<const float4 *>(wl + (i - lb));
+                    d = make_float4(d.x * w.x, d.y * w.y, d.z * w.z, d.w * w.w);
+                }
+            } else {
+                int rb = N / 2 + N / 4 - (rn >> 2);
+                if (i >= rb + (rn >> 1)) d = make_float4(0.f, 0.f, 0.f, 0.f);
+                else if (i >= rb) {
+                    float4 w = *reinterpret_cast<const float4 *>(wr + ((rn >> 1) - 4 - (i - rb)));
+                    d = make_float4(d.x * w.w, d.y * w.z, d.z * w.y, d.w * w.x);
+                }
+            }
+            *reinterpret_cast<float4 *>(c + i) = d;
+        }
+        wave_lds_sync();
+
+        fft_forward<N>(c, ch, s_wa, lane);
+
+        // ---- log power spectrum + block maximum (lib/mapping0.c:848-888) -----------------
+        float *o = logfft + blk * (N / 2);
+        float mx;
+        {
+            // bin 0 by lane 0; its value seeds the running maximum (:862)
+            float v0 = (float)((double)(scale_dB + todB(c[0])) + .345);
+            mx = v0;
+            if (lane == 0) o[0] = v0;
+        }
+        for (int m = 1 + lane; m < N / 2; m += 64) {
+            int j = 2 * m - 1;
+            float re = c[j], im = c[j + 1];
+            float temp = re * re + im * im;
+            float v = (float)((double)(scale_dB + .5f * todB(temp)) + .345);
+            o[m] = v;
+            if (v > mx) mx = v;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            float other = __shfl_xor(mx, off);
+            if (other > mx) mx = other;
+        }
+        if (mx > 0.f) mx = 0.f;
+        if (lane == 0) local_ampmax[blk] = mx;
+        wave_lds_sync();
+    }
+}
+
+}  // namespace
+
+extern "C" int vbm_launch_window_fft_log(const float *d_pcm, float *d_logfft, float *d_local_ampmax,
+                                         const uint8_t *d_wflags, const float *d_wa, const float *d_win_self,
+                                         const float *d_win_short, int n, int short_n, long nblocks,
+                                         hipStream_t stream)
+{
+    if (nblocks <= 0) return 0;
+    if (n != 2048 && n != 256) return -1;
+    long wgs = (nblocks + WAVES_PER_WG - 1) / WAVES_PER_WG;
+    if (wgs > 256 * 2) wgs = 256 * 2;
+    dim3 grid((unsigned)wgs), block(64 * WAVES_PER_WG);
+    if (n == 2048)
+        hipLaunchKernelGGL(k_window_fft_log<2048>, grid, block, 0, stream, d_pcm, d_logfft, d_local_ampmax,
+                           d_wflags, d_wa, d_win_self, d_win_short, short_n, nblocks);
+    else
+        hipLaunchKernelGGL(k_window_fft_log<256>, grid, block, 0, stream, d_pcm, d_logfft, d_local_ampmax,
+                           d_wflags, d_wa, d_win_self, d_win_short, short_n, nblocks);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}

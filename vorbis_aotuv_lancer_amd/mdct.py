@@ -33,6 +33,11 @@ class MdctLookup:
         p = lib.vbm_mdct_plan_trig(self._h)
         return np.ctypeslib.as_array(p, shape=(self.n + self.n // 4,)).copy()
 
+    @property
+    def fft_twiddles(self):
+        p = lib.vbm_mdct_plan_fft_twiddles(self._h)
+        return np.ctypeslib.as_array(p, shape=(self.n,)).copy()
+
     def close(self):
         if self._h:
             lib.vbm_mdct_plan_destroy(self._h)
@@ -81,3 +86,19 @@ def window_mdct(lookup, pcm, wflags=None, out=None):
     check(lib.vbm_window_mdct_batch(lookup._h, pcm.data_ptr(), out.data_ptr(), fp, nb, _stream()),
           "vbm_window_mdct_batch")
     return out
+
+
+def window_fft_log(lookup, pcm, wflags=None):
+    """_vorbis_apply_window + drft_forward + log-power spectrum (lib/mapping0.c:825-888).
+    Returns (logfft (…, n/2), local_ampmax (…,))."""
+    nb = _prep(lookup, pcm)
+    logfft = torch.empty(pcm.shape[:-1] + (lookup.n // 2,), dtype=torch.float32, device=pcm.device)
+    amp = torch.empty(pcm.shape[:-1], dtype=torch.float32, device=pcm.device)
+    fp = None
+    if wflags is not None:
+        if not (wflags.is_cuda and wflags.dtype == torch.uint8 and wflags.numel() == nb):
+            raise ValueError("wflags must be a uint8 CUDA tensor with one entry per block")
+        fp = wflags.data_ptr()
+    check(lib.vbm_window_fft_log_batch(lookup._h, pcm.data_ptr(), logfft.data_ptr(), amp.data_ptr(), fp, nb,
+                                       _stream()), "vbm_window_fft_log_batch")
+    return logfft, amp

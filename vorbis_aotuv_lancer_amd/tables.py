@@ -36,4 +36,4 @@ def pack(name):
 def window_table(n):
     """Rising half-window (n/2 floats) of an n-sample block — the reference's vwin tables
     (lib/window.c:29-2122) taken verbatim."""
-    return pack("windows.vpk")[f"window/{n}"]
+    return pack("common.vpk")[f"window/{n}"]
