@@ -88,6 +88,24 @@ int vbm_window_fft_log_batch(const vbm_mdct_plan *plan, const float *d_pcm, floa
 /* host copy of the FFTPACK twiddle table (n floats = drft_lookup.trigcache + n) — for parity tests */
 const float *vbm_mdct_plan_fft_twiddles(const vbm_mdct_plan *plan);
 
+/* ---- encoder setup ----------------------------------------------------------------------
+ * vbm_setup replaces codec_setup_info + the looks of private_state that vorbis_analysis_init()
+ * builds (lib/block.c:181-331: _vp_psy_init, floor1_look, res0_look, vorbis_book_init_encode,
+ * mdct_init, drft_init).  It is created from two VPK packs shipped with the package:
+ *   common_vpk : static tables (windows, ATH, tone masks, dB lookup …)   data/common.vpk
+ *   mode_vpk   : the (channels, rate, quality) class, i.e. the output of
+ *                vorbis_encode_init_vbr (lib/vorbisenc.c:977)           data/mode_*.vpk
+ * Creation is host-only; tables are uploaded when an encoder is created on a device. */
+typedef struct vbm_setup_handle vbm_setup_handle;
+int vbm_setup_create(vbm_setup_handle **setup, const char *common_vpk, const char *mode_vpk);
+void vbm_setup_destroy(vbm_setup_handle *setup);
+/* Introspection of the derived look tables by name ("psy/3/ath", "floor/1/sorted_index",
+ * "book/7/codelist", "residue/0/partbook", "info", …) for parity checks; *kind is one of
+ * 'f' float32, 'i' int32, 'u' uint32, 'b' int8, 'd' float64.  The pointer stays valid until the
+ * next call on the same thread (scalars) or until the setup is destroyed (arrays). */
+int vbm_setup_table(const vbm_setup_handle *setup, const char *name, const void **data, long *count,
+                    char *kind);
+
 /* Host-only table builders (no device needed): the lookup tables the plans upload, for
  * integrators and for CPU-side parity checks.
  *   vbm_host_mdct_trig     n + n/4 floats  (mdct_init, lib/mdct.c:67-76)

@@ -235,6 +235,7 @@ typedef struct orc_setup {
 
 orc_setup *orc_setup_load(const char *common_vpk, const char *mode_vpk);
 void orc_setup_free(orc_setup *s);
+int orc_setup_table(const orc_setup *s, const char *name, const void **data, long *count, char *kind);
 
 /* ---- stage functions (same argument meaning as the reference externs, lib/psy.h:188-242) */
 float orc_postnoise_detection(const float *pcm, int nn, int mode, int lw_mode);

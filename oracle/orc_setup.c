@@ -581,3 +581,78 @@ void orc_setup_free(orc_setup *s)
         if (s->packs[i]) { vpk_close((vpk_file *)s->packs[i]); free(s->packs[i]); }
     free(s);
 }
+
+/* name-based access to the derived tables, for comparing the product's host tables with the
+ * oracle's (tests/test_setup_tables.py).  kind: 'f' float32, 'i' int32, 'q' int64, 'u' uint32, 'b' int8 */
+int orc_setup_table(const orc_setup *s, const char *name, const void **data, long *count, char *kind)
+{
+    int idx = -1;
+    char leaf[64] = {0};
+    static int sc[16];
+#define RET(ptr, n, k) do { *data = (ptr); *count = (long)(n); *kind = (k); return 0; } while (0)
+    if (sscanf(name, "psy/%d/%63s", &idx, leaf) == 2 && idx >= 0 && idx < s->psys) {
+        const orc_psy *p = &s->psy[idx];
+        if (!strcmp(leaf, "ath")) RET(p->ath, p->n, 'f');
+        if (!strcmp(leaf, "octave")) RET(p->octave, p->n, 'q');
+        if (!strcmp(leaf, "bark")) RET(p->bark, p->n, 'q');
+        if (!strcmp(leaf, "tonecurves")) RET(p->tonecurves, ORC_P_BANDS * ORC_P_LEVELS * (ORC_EHMER_MAX + 2), 'f');
+        if (!strcmp(leaf, "noiseoffset0")) RET(p->noiseoffset[0], p->n, 'f');
+        if (!strcmp(leaf, "noiseoffset1")) RET(p->noiseoffset[1], p->n, 'f');
+        if (!strcmp(leaf, "noiseoffset2")) RET(p->noiseoffset[2], p->n, 'f');
+        if (!strcmp(leaf, "ntfix_noiseoffset")) RET(p->ntfix_noiseoffset, p->n, 'f');
+        if (!strcmp(leaf, "scalars")) {
+            union { float f; int i; } u;
+            int v[16] = {p->n, (int)p->firstoc, (int)p->shiftoc, p->eighth_octave_lines, p->total_octave_lines,
+                         p->m3n[0], p->m3n[1], p->m3n[2], p->tonecomp_endp, p->min_nn_lp, p->tonefix_end,
+                         p->n25p, p->n33p, p->n75p, 0, 0};
+            memcpy(sc, v, sizeof(v));
+            u.f = p->m_val; sc[14] = u.i;
+            u.f = p->tonecomp_thres; sc[15] = u.i;
+            RET(sc, 16, 'i');
+        }
+    }
+    if (sscanf(name, "floor/%d/%63s", &idx, leaf) == 2 && idx >= 0 && idx < s->floors) {
+        const orc_floor *f = &s->floor[idx];
+        if (!strcmp(leaf, "sorted_index")) RET(f->sorted_index, f->posts, 'i');
+        if (!strcmp(leaf, "forward_index")) RET(f->forward_index, f->posts, 'i');
+        if (!strcmp(leaf, "reverse_index")) RET(f->reverse_index, f->posts, 'i');
+        if (!strcmp(leaf, "loneighbor")) RET(f->loneighbor, f->posts - 2, 'i');
+        if (!strcmp(leaf, "hineighbor")) RET(f->hineighbor, f->posts - 2, 'i');
+        if (!strcmp(leaf, "scalars")) {
+            sc[0] = f->posts; sc[1] = f->n; sc[2] = f->quant_q; sc[3] = f->info_n;
+            RET(sc, 4, 'i');
+        }
+    }
+    if (sscanf(name, "book/%d/%63s", &idx, leaf) == 2 && idx >= 0 && idx < s->books) {
+        const orc_book *b = &s->book[idx];
+        if (!strcmp(leaf, "codelist")) RET(b->codelist, b->entries, 'u');
+        if (!strcmp(leaf, "lengthlist")) RET(b->lengthlist, b->entries, 'b');
+        if (!strcmp(leaf, "scalars")) {
+            sc[0] = b->dim; sc[1] = b->entries; sc[2] = b->quantvals; sc[3] = b->minval; sc[4] = b->delta; sc[5] = 0;
+            RET(sc, 6, 'i');
+        }
+    }
+    if (sscanf(name, "residue/%d/%63s", &idx, leaf) == 2 && idx >= 0 && idx < s->residues) {
+        const orc_residue *r = &s->residue[idx];
+        if (!strcmp(leaf, "partbook")) {
+            static int pb[64 * 8];
+            int j, k;
+            for (j = 0; j < 64; j++)
+                for (k = 0; k < 8; k++) pb[j * 8 + k] = r->partbooks[j][k] ? (int)(r->partbooks[j][k] - s->book) : -1;
+            RET(pb, 64 * 8, 'i');
+        }
+        if (!strcmp(leaf, "scalars")) {
+            sc[0] = r->type; sc[1] = (int)r->begin; sc[2] = (int)r->end; sc[3] = r->grouping; sc[4] = r->partitions;
+            sc[5] = r->groupbook; sc[6] = r->stages; sc[7] = r->phrasebook->dim;
+            RET(sc, 8, 'i');
+        }
+    }
+    if (!strcmp(name, "info")) {
+        int v[12] = {s->channels, (int)s->rate, (int)s->blocksizes[0], (int)s->blocksizes[1], s->modes, s->maps,
+                     s->floors, s->residues, s->books, s->psys, s->block_lowpassr[0], s->block_lowpassr[1]};
+        memcpy(sc, v, sizeof(v));
+        RET(sc, 12, 'i');
+    }
+#undef RET
+    return -1;
+}

@@ -35,6 +35,10 @@ SIGNATURES = {
     "vbm_window_fft_log_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long,
                                            C.c_void_p]),
     "vbm_mdct_plan_fft_twiddles": (_c_float_p, [C.c_void_p]),
+    "vbm_setup_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_char_p, C.c_char_p]),
+    "vbm_setup_destroy": (None, [C.c_void_p]),
+    "vbm_setup_table": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_long),
+                                  C.POINTER(C.c_char)]),
     "vbm_host_mdct_trig": (C.c_int, [C.c_int, C.c_void_p]),
     "vbm_host_fft_twiddles": (C.c_int, [C.c_int, C.c_void_p]),
     "vbm_window_mdct_time": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int,

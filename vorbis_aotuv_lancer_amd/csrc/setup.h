@@ -1,0 +1,122 @@
+// Encoder setup shared by the host code and the kernels: plain-old-data views of everything
+// the reference keeps in codec_setup_info + the looks built by vorbis_analysis_init()
+// (reference lib/codec_internal.h:101-136, lib/psy.h:96-151, lib/block.c:181-303).
+// Pointers inside these structs are HOST pointers in the host copy and DEVICE pointers in the
+// device copy (one arena upload, pointers rebased).
+#pragma once
+#include <stdint.h>
+
+#define VBM_PACKETBLOBS 15
+#define VBM_P_BANDS 17
+#define VBM_P_LEVELS 8
+#define VBM_P_NOISECURVES 3
+#define VBM_NOISE_COMPAND_LEVELS 40
+#define VBM_EHMER_MAX 56
+#define VBM_EHMER_OFFSET 16
+#define VBM_MAX_ATH 88
+#define VBM_VIF_POSIT 63
+#define VBM_MAXCH 8
+#define VBM_MAX_BOOK_DIM 8
+
+struct vbm_psy {                 // vorbis_info_psy + vorbis_look_psy
+    int blockflag;
+    float ath_adjatt, ath_maxatt;
+    float tone_masteratt[VBM_P_NOISECURVES];
+    float tone_centerboost, tone_decay, tone_abs_limit;
+    float toneatt[VBM_P_BANDS];
+    int noisemaskp;
+    float noisemaxsupp, noisewindowlo, noisewindowhi;
+    int noisewindowlomin, noisewindowhimin, noisewindowfixed;
+    float noiseoff[VBM_P_NOISECURVES][VBM_P_BANDS];
+    float noisecompand[VBM_NOISE_COMPAND_LEVELS], noisecompand_high[VBM_NOISE_COMPAND_LEVELS];
+    float flacint, max_curve_dB;
+    int normal_p, normal_start, normal_partition;
+    double normal_thresh;
+    // look
+    int n;
+    long rate;
+    int firstoc, shiftoc, eighth_octave_lines, total_octave_lines;
+    int m3n[4];
+    float m_val;
+    int tonecomp_endp;
+    float tonecomp_thres;
+    int min_nn_lp, tonefix_end;
+    int n25p, n33p, n75p;
+    const float *tonecurves;         // [P_BANDS][P_LEVELS][EHMER_MAX+2]
+    const float *noiseoffset[VBM_P_NOISECURVES];  // n each
+    const float *ath;                // n
+    const int *octave;               // n
+    const int *bark_lo, *bark_hi;    // n each: lib/psy.c:471 packs ((lo-1)<<16)+(hi-1); kept unpacked-as-read
+    const float *ntfix_noiseoffset;  // n
+};
+
+struct vbm_floor {               // vorbis_info_floor1 + vorbis_look_floor1
+    int partitions;
+    int partitionclass[31];
+    int class_dim[16], class_subs[16], class_book[16], class_subbook[16][8];
+    int mult;
+    int postlist[VBM_VIF_POSIT + 2];
+    float maxover, maxunder, maxerr, twofitweight, twofitatten;
+    int info_n;
+    int sorted_index[VBM_VIF_POSIT + 2], forward_index[VBM_VIF_POSIT + 2], reverse_index[VBM_VIF_POSIT + 2];
+    int hineighbor[VBM_VIF_POSIT], loneighbor[VBM_VIF_POSIT];
+    int posts, n, quant_q;
+};
+
+struct vbm_book {                // static_codebook + encode side of codebook
+    int dim, entries;
+    int quantvals, minval, delta;
+    const signed char *lengthlist;   // entries
+    const uint32_t *codelist;        // entries (bit-reversed words)
+    // compact list of the entries that have a codeword, in ascending entry order, with their
+    // lattice points — the exhaustive search of lib/res0.c:343-370 visits exactly these
+    int used;
+    const int *used_index;           // used
+    const int *used_point;           // used x dim
+};
+
+struct vbm_residue {             // vorbis_info_residue0 + look
+    int type;
+    int begin, end;
+    int grouping, partitions, groupbook;
+    int secondstages[64];
+    int classmetric1[64], classmetric2[64];
+    int stages, phrase_dim;
+    int partbook[64][8];             // book index or -1
+};
+
+struct vbm_map {
+    int submaps;
+    int chmuxlist[VBM_MAXCH];
+    int floorsubmap[16], residuesubmap[16];
+    int coupling_steps;
+    int coupling_mag[16], coupling_ang[16];
+};
+
+struct vbm_setup {
+    int channels;
+    long rate;
+    int blocksizes[2];
+    int modes, maps, floors, residues, books, psys;
+    int modebits;
+    int block_lowpassr[2];
+    float pre_amplitude;
+    vbm_map map[2];
+    vbm_floor floor[4];
+    vbm_residue residue[4];
+    vbm_psy psy[4];
+    const vbm_book *book;            // books
+    // vorbis_info_psy_global (the parts the per-block path reads)
+    int coupling_pointlimit[2][VBM_PACKETBLOBS];
+    int coupling_prepointamp[VBM_PACKETBLOBS], coupling_postpointamp[VBM_PACKETBLOBS];
+    int sliding_lowpass[2][VBM_PACKETBLOBS];
+    float ampmax_att_per_sec;
+    // static tables
+    double stereo_threshholds[9], stereo_threshholds_X[9];
+    int stn_compand[VBM_NOISE_COMPAND_LEVELS];
+    const int *freq_bfn128, *freq_bfn256;
+    const float *fromdB;             // 256
+    const float *window[2];          // rising half-windows of blocksizes[0], [1]
+    const float *mdct_trig[2];       // n + n/4
+    const float *fft_wa[2];          // n
+};
