@@ -43,7 +43,7 @@ def test_product_never_imports_oracle():
         for f in files:
             if f.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
                 t = open(os.path.join(dp, f), errors="replace").read()
-                if re.search(r"liboracle|oracle/|import\s+orc\b|from\s+tests", t):
+                if re.search(r"liboracle|#\s*include\s*[\"<][^\">]*orac|oracle/|import\s+orc\b|from\s+tests", t):
                     bad.append(os.path.join(dp, f))
     assert not bad, bad
 

@@ -2,7 +2,7 @@
 // per-class lookup tables the reference builds in vorbis_analysis_init(), and lays everything
 // out in one arena that is uploaded to the device unchanged (pointers rebased).
 //
-// Look derivations restated here (product code, independent of oracle/):
+// Look derivations restated here (product code; shares nothing with the test checker):
 //   _vp_psy_init        reference lib/psy.c:352-507
 //   setup_tone_curves   lib/psy.c:171-350
 //   floor1_look         lib/floor1.c:183-258
