@@ -106,6 +106,42 @@ void vbm_setup_destroy(vbm_setup_handle *setup);
 int vbm_setup_table(const vbm_setup_handle *setup, const char *name, const void **data, long *count,
                     char *kind);
 
+/* ---- batched analysis ---------------------------------------------------------------------
+ * vbm_encoder holds, on the device, the carried per-stream encoder state of `nstreams` streams
+ * (private_state's aoTuV fields mblock/tblock/lownoise_compand_level/lW_block_mode/lW_no/impadnum,
+ * lib/codec_internal.h:85-92; vorbis_block_internal.ampmax and vorbis_look_psy_global.ampmax)
+ * plus the workspace for batches of up to `max_batch` blocks.
+ *
+ * vbm_analysis_batch() is the batched form of the reference's per-block sequence
+ *     vorbis_analysis(vb, NULL)            lib/analysis.c:29   -> mapping0_forward lib/mapping0.c:738
+ *     vorbis_bitrate_addblock(vb)          lib/bitrate.c:73    (VBR: parks the block)
+ *     vorbis_bitrate_flushpacket(vd, &op)  lib/bitrate.c:229   (VBR: packetblob[PACKETBLOBS/2])
+ * for `nsb` blocks that share one block type, at most one block per stream and call, in the
+ * stream's block order (blocks of one stream are order dependent).
+ *   block_mode   0 impulse short, 1 padding short, 2 transition long, 3 long
+ *                (= blocktype | W<<1, lib/mapping0.c:768-775; vbi->blocktype from lib/block.c:620-638)
+ *   stream_ids   host array [nsb]: which stream each block belongs to
+ *   wflags       host array [nsb]: bit0 = vb->lW, bit1 = vb->nW
+ *   d_pcm        device, [nsb][channels][blocksize] floats: vb->pcm as vorbis_analysis_blockout
+ *                hands it over (un-windowed, lib/block.c:653-698)
+ *   d_packets    device, [nsb][vbm_encoder_max_packet_bytes()] bytes: op->packet of every block
+ *   d_packet_bytes device, [nsb] ints: op->bytes (or -1 if a packet outgrew the buffer)
+ * Managed-bitrate mode (15 packetblobs) is not implemented: VBM_EIMPL from create if the mode
+ * pack asks for it. */
+typedef struct vbm_encoder vbm_encoder;
+int vbm_encoder_create(vbm_encoder **enc, vbm_setup_handle *setup, int nstreams, int max_batch);
+void vbm_encoder_destroy(vbm_encoder *enc);
+int vbm_encoder_reset(vbm_encoder *enc); /* back to the state after vorbis_analysis_init */
+int vbm_encoder_max_packet_bytes(const vbm_encoder *enc);
+int vbm_analysis_batch(vbm_encoder *enc, int block_mode, int nsb, const int *stream_ids,
+                       const uint8_t *wflags, const float *d_pcm, uint8_t *d_packets,
+                       int *d_packet_bytes, void *stream);
+/* Stage intermediates of the LAST batch as block-major rows ([channel-block][rows]) for parity
+ * tests: "mdct_raw" "logfft" "logmdct" "noise" "tone" "logmask" "mdct" "epeak" "npeak" "post"
+ * "floor_out" "residue", and the vectors "local_ampmax" "global_ampmax" "post_valid" "nonzero"
+ * "poste" "packet_bytes".  d_out may be NULL to query rows/kind ('f' float32, 'i' int32). */
+int vbm_encoder_fetch(vbm_encoder *enc, const char *name, void *d_out, long *rows, char *kind, void *stream);
+
 /* Host-only table builders (no device needed): the lookup tables the plans upload, for
  * integrators and for CPU-side parity checks.
  *   vbm_host_mdct_trig     n + n/4 floats  (mdct_init, lib/mdct.c:67-76)

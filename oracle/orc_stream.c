@@ -343,3 +343,35 @@ long orc_encode_probe(const orc_setup *s, int secs, const char *out_path, double
     orc_stream_free(v);
     return npk;
 }
+
+/* ---- accessors for the Python test harness (tests/orc.py) -------------------------------- */
+void orc_stream_set_capture(orc_stream *v, int on) { v->capture = on; }
+
+void orc_block_info(const orc_block *vb, int *out)
+{
+    out[0] = vb->lW; out[1] = vb->W; out[2] = vb->nW; out[3] = vb->blocktype; out[4] = vb->pcmend;
+    out[5] = vb->cap_block_mode; out[6] = vb->eofflag;
+}
+
+const void *orc_block_cap(const orc_block *vb, const char *name, int ch)
+{
+    if (!strcmp(name, "pcm")) return vb->pcmbuf[ch];
+    if (!strcmp(name, "windowed")) return vb->cap_windowed[ch];
+    if (!strcmp(name, "mdct_raw")) return vb->cap_gmdct_raw[ch];
+    if (!strcmp(name, "mdct")) return vb->cap_gmdct[ch];
+    if (!strcmp(name, "logfft")) return vb->cap_logfft[ch];
+    if (!strcmp(name, "logmdct")) return vb->cap_logmdct[ch];
+    if (!strcmp(name, "noise")) return vb->cap_noise[ch];
+    if (!strcmp(name, "tone")) return vb->cap_tone[ch];
+    if (!strcmp(name, "logmask")) return vb->cap_logmask[ch];
+    if (!strcmp(name, "epeak")) return vb->cap_epeak[ch];
+    if (!strcmp(name, "npeak")) return vb->cap_npeak[ch];
+    if (!strcmp(name, "ilogmask")) return vb->cap_ilogmask[ch];
+    if (!strcmp(name, "residue")) return vb->cap_residue[ch];
+    if (!strcmp(name, "post")) return vb->cap_post[ch];
+    if (!strcmp(name, "post_valid")) return &vb->cap_post_valid[ch];
+    if (!strcmp(name, "nonzero")) return &vb->cap_nonzero[ch];
+    if (!strcmp(name, "local_ampmax")) return &vb->cap_local_ampmax[ch];
+    if (!strcmp(name, "global_ampmax")) return &vb->cap_global_ampmax;
+    return 0;
+}

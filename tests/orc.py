@@ -113,3 +113,105 @@ def fft_logpower(oracle, windowed):
     for i in range(flat.shape[0]):
         amp[i] = oracle.lib.orc_fft_logpower(C.byref(d), _p(flat[i]), n)
     return flat[:, :n // 2].reshape(x.shape[:-1] + (n // 2,)).copy(), amp.reshape(x.shape[:-1])
+
+
+class Stream:
+    """One oracle encoder stream with stage capture (orc_stream + orc_block)."""
+
+    def __init__(self, setup):
+        self.setup = setup
+        lib = self.lib = setup.o.lib
+        lib.orc_stream_new.restype = C.c_void_p
+        lib.orc_stream_new.argtypes = [C.c_void_p]
+        lib.orc_block_new.restype = C.c_void_p
+        lib.orc_block_new.argtypes = [C.c_void_p]
+        lib.orc_analysis_buffer.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        lib.orc_analysis_wrote.argtypes = [C.c_void_p, C.c_int]
+        lib.orc_analysis_blockout.argtypes = [C.c_void_p, C.c_void_p]
+        lib.orc_analysis.argtypes = [C.c_void_p, C.c_void_p]
+        lib.orc_block_packet.restype = C.POINTER(C.c_ubyte)
+        lib.orc_block_packet.argtypes = [C.c_void_p, C.POINTER(C.c_long)]
+        lib.orc_block_info.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        lib.orc_block_cap.restype = C.c_void_p
+        lib.orc_block_cap.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        lib.orc_stream_set_capture.argtypes = [C.c_void_p, C.c_int]
+        lib.orc_stream_free.argtypes = [C.c_void_p]
+        lib.orc_block_free.argtypes = [C.c_void_p]
+        self.v = lib.orc_stream_new(setup.h)
+        self.vb = lib.orc_block_new(setup.h)
+        lib.orc_stream_set_capture(self.v, 1)
+        self.ch = setup.ch
+
+    def write(self, pcm):
+        """pcm: (ch, n) float32"""
+        pcm = np.ascontiguousarray(pcm, np.float32)
+        n = pcm.shape[1]
+        bufs = (C.c_void_p * 8)()
+        self.lib.orc_analysis_buffer(self.v, n, bufs)
+        for c in range(self.ch):
+            C.memmove(bufs[c], pcm[c].ctypes.data, n * 4)
+        self.lib.orc_analysis_wrote(self.v, n)
+
+    def _arr(self, name, c, count, dtype):
+        p = self.lib.orc_block_cap(self.vb, name.encode(), c)
+        buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(p)
+        return np.frombuffer(buf, dtype=dtype).copy()
+
+    def blocks(self):
+        """Drain ready blocks: yields dicts with the raw block PCM, the block flags, every
+        captured stage vector and the packet."""
+        info = (C.c_int * 8)()
+        while self.lib.orc_analysis_blockout(self.v, self.vb) == 1:
+            self.lib.orc_block_info(self.vb, info)
+            N = info[4]
+            pcm = np.stack([self._arr("pcm", c, N, np.float32) for c in range(self.ch)])
+            self.lib.orc_analysis(self.v, self.vb)
+            self.lib.orc_block_info(self.vb, info)
+            n = N // 2
+            nb = C.c_long()
+            pk = self.lib.orc_block_packet(self.vb, C.byref(nb))
+            d = {"lW": info[0], "W": info[1], "nW": info[2], "blocktype": info[3], "N": N,
+                 "block_mode": info[5], "pcm": pcm, "packet": bytes(pk[:nb.value])}
+            for name in ("mdct_raw", "mdct", "logfft", "logmdct", "noise", "tone", "logmask", "epeak"):
+                d[name] = np.stack([self._arr(name, c, n, np.float32) for c in range(self.ch)])
+            for name in ("ilogmask", "residue"):
+                d[name] = np.stack([self._arr(name, c, n, np.int32) for c in range(self.ch)])
+            d["post"] = np.stack([self._arr("post", c, 65, np.int32) for c in range(self.ch)])
+            d["post_valid"] = np.array([self._arr("post_valid", c, 1, np.int32)[0] for c in range(self.ch)])
+            d["nonzero"] = np.array([self._arr("nonzero", c, 1, np.int32)[0] for c in range(self.ch)])
+            d["local_ampmax"] = np.array([self._arr("local_ampmax", c, 1, np.float32)[0] for c in range(self.ch)])
+            d["global_ampmax"] = self._arr("global_ampmax", 0, 1, np.float32)[0]
+            yield d
+
+    def close(self):
+        self.lib.orc_stream_free(self.v)
+        self.lib.orc_block_free(self.vb)
+
+
+def probe_signal(ch, rate, nsamples, seed=12345, amp=1.0, f0=440.0):
+    """The survey probe signal with a per-stream seed / pitch."""
+    lcg = np.uint32(seed)
+    out = np.empty((ch, nsamples), np.float32)
+    t = np.arange(nsamples, dtype=np.float64) / rate
+    pos = np.arange(nsamples)
+    burst = ((pos // (rate // 3)) % 4 == 3) & ((pos % (rate // 3)) < 200)
+    # LCG draws: per sample, per channel: one noise draw, plus one more when in a burst
+    draws_per = ch * (1 + burst.astype(np.int64))
+    total = int(draws_per.sum())
+    x = np.empty(total, np.uint32)
+    s = int(lcg)
+    for i in range(total):
+        s = (s * 1664525 + 1013904223) & 0xffffffff
+        x[i] = s
+    r = (((x >> 8) & 0xffff).astype(np.float32) / np.float32(32768.0)) - np.float32(1.0)
+    k = 0
+    starts = np.concatenate([[0], np.cumsum(draws_per)[:-1]])
+    for c in range(ch):
+        base = 0.3 * np.sin(2 * np.pi * f0 * (c + 1) * t) + 0.2 * np.sin(2 * np.pi * 3000.0 * t + c)
+        step = 1 + burst.astype(np.int64)
+        idx = starts + c * step
+        smp = (np.float32(0.3) * 0 + base) + (np.float32(0.05) * r[idx]).astype(np.float64)
+        smp = smp.astype(np.float32)
+        smp = np.where(burst, (smp.astype(np.float64) * 0 + smp + (np.float32(0.6) * r[idx + 1])).astype(np.float32), smp)
+        out[c] = smp * np.float32(amp)
+    return out

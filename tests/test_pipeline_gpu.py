@@ -1,0 +1,98 @@
+"""Full device pipeline vs the oracle: stage by stage and packet by packet.
+
+NS independent streams are encoded by the oracle on the CPU (block sequence, raw block PCM,
+every captured stage vector, packets).  The same blocks are then pushed through
+vbm_analysis_batch in lock-step (k-th block of every stream per step, grouped by block type),
+and every intermediate the C ABI exposes is compared bit-for-bit."""
+import numpy as np
+import pytest
+import torch
+
+from tests import orc
+from tests.signals import synth_signal
+
+pytestmark = pytest.mark.gpu
+
+STAGES_F = ["mdct_raw", "logfft", "logmdct", "noise", "tone", "logmask", "mdct"]
+
+
+def oracle_blocks(oracle, ch, rate, q, seconds, seed):
+    setup = orc.Setup(oracle, ch, rate, q)
+    st = orc.Stream(setup)
+    sig = synth_signal(ch, rate, int(seconds * rate), seed=seed, level=1.0 if seed % 3 else 0.05)
+    out = []
+    for i in range(0, sig.shape[1], 1024):
+        st.write(sig[:, i:i + 1024])
+        out.extend(st.blocks())
+    st.close()
+    return out
+
+
+def run_case(oracle, cuda, ch, rate, q, nstreams, seconds, check_stages=True, res1_channels=()):
+    import vorbis_aotuv_lancer_amd as v
+    streams = [oracle_blocks(oracle, ch, rate, q, seconds, seed=100 + s) for s in range(nstreams)]
+    nsteps = min(len(b) for b in streams)
+    assert nsteps > 20
+    setup = v.Setup(ch, rate, q)
+    enc = v.Encoder(setup, nstreams)
+    seen_modes = set()
+    mismatches = []
+    for k in range(nsteps):
+        by_mode = {}
+        for s in range(nstreams):
+            by_mode.setdefault(streams[s][k]["block_mode"], []).append(s)
+        for mode, ids in sorted(by_mode.items()):
+            seen_modes.add(mode)
+            blks = [streams[s][k] for s in ids]
+            pcm = torch.from_numpy(np.stack([b["pcm"] for b in blks])).to(cuda)
+            wflags = [b["lW"] | (b["nW"] << 1) for b in blks]
+            packets, nbytes = enc.analysis_batch(mode, ids, wflags, pcm)
+            nbytes = nbytes.cpu().numpy()
+            packets = packets.cpu().numpy()
+            if check_stages:
+                for name in STAGES_F:
+                    got = enc.fetch(name).cpu().numpy().view(np.uint32)
+                    ref = np.concatenate([b[name] for b in blks]).view(np.uint32)
+                    if not np.array_equal(got, ref):
+                        bad = np.argwhere(got != ref)[0]
+                        mismatches.append((k, mode, name, tuple(bad)))
+                got = enc.fetch("post_valid").cpu().numpy()
+                ref = np.concatenate([b["post_valid"] for b in blks])
+                if not np.array_equal(got, ref):
+                    mismatches.append((k, mode, "post_valid", ()))
+                got = enc.fetch("residue").cpu().numpy()
+                ref = np.concatenate([b["residue"] for b in blks])
+                if res1_channels:
+                    # res-1 encodes in place (lib/res0.c:372-375 on in[j] itself): after the packet
+                    # kernel those channels hold the VQ remainder, not the quantised residue
+                    keep = np.array([c not in res1_channels for c in range(ch)] * len(blks))
+                    got, ref = got[keep], ref[keep]
+                if not np.array_equal(got, ref):
+                    mismatches.append((k, mode, "residue", tuple(np.argwhere(got != ref)[0])))
+                got = enc.fetch("nonzero").cpu().numpy()
+                ref = np.concatenate([b["nonzero"] for b in blks])
+                if not np.array_equal(got, ref):
+                    mismatches.append((k, mode, "nonzero", ()))
+            for i, b in enumerate(blks):
+                pk = bytes(packets[i, :max(nbytes[i], 0)])
+                if nbytes[i] != len(b["packet"]) or pk != b["packet"]:
+                    mismatches.append((k, mode, "packet", (ids[i], int(nbytes[i]), len(b["packet"]))))
+            assert not mismatches, mismatches[:8]
+    enc.close()
+    setup.close()
+    return seen_modes, nsteps
+
+
+def test_stereo_q5_stage_and_packet_parity(oracle, cuda):
+    modes, nsteps = run_case(oracle, cuda, 2, 44100, 0.5, nstreams=24, seconds=4.0)
+    assert modes == {0, 1, 2, 3}     # impulse, padding, transition and long blocks all occurred
+
+
+def test_stereo_q1_packet_parity(oracle, cuda):
+    # q0.1: live noise normalisation (normal_start 16/128) and the 128x4 short floor
+    run_case(oracle, cuda, 2, 44100, 0.1, nstreams=8, seconds=3.0)
+
+
+def test_surround_51_q8_packet_parity(oracle, cuda):
+    # 6 channels, two submaps: 5-channel res-2 (uncoupled) + LFE res-1
+    run_case(oracle, cuda, 6, 48000, 0.8, nstreams=6, seconds=3.0, res1_channels=(5,))

@@ -39,6 +39,14 @@ SIGNATURES = {
     "vbm_setup_destroy": (None, [C.c_void_p]),
     "vbm_setup_table": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_long),
                                   C.POINTER(C.c_char)]),
+    "vbm_encoder_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int]),
+    "vbm_encoder_destroy": (None, [C.c_void_p]),
+    "vbm_encoder_reset": (C.c_int, [C.c_void_p]),
+    "vbm_encoder_max_packet_bytes": (C.c_int, [C.c_void_p]),
+    "vbm_analysis_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]),
+    "vbm_encoder_fetch": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_char),
+                                    C.c_void_p]),
     "vbm_host_mdct_trig": (C.c_int, [C.c_int, C.c_void_p]),
     "vbm_host_fft_twiddles": (C.c_int, [C.c_int, C.c_void_p]),
     "vbm_window_mdct_time": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int,

@@ -1,0 +1,79 @@
+// Device-side view of one homogeneous batch: `nsb` stream-blocks of the same block_mode
+// (0 impulse, 1 padding, 2 transition, 3 long — reference lib/mapping0.c:768-775), each with
+// `ch` channels.  The serial stages of the encode path run one LANE per channel-block
+// (psy, floor) or per stream-block (couple/quantise, residue, bit packing): 64 independent
+// blocks per wavefront, all walking the same table-driven loops in lockstep.  To keep those
+// accesses coalesced every per-bin array is stored bin-major ("transposed"):
+//     X[bin][L]   with L = channel-block count rounded up to 64,
+// so lane l reads X[bin*L + l] — 256 contiguous bytes per wave-instruction.
+// Block-major arrays (pcm, mdct_bm, logfft_bm) are the interface to the wave-per-block
+// transform kernels; transposes go through LDS tiles (util_kernels.hip).
+#pragma once
+#include <stdint.h>
+#include "setup.h"
+
+struct vbm_stream_state {           // per-encoder, S streams (reference lib/codec_internal.h:85-92,
+    int S, ch;                      //  vorbis_block_internal.ampmax, vorbis_look_psy_global.ampmax)
+    int Lc;                         // S*ch rounded up to 64: leading dimension of the per-channel arrays
+    float *mblock;                  // [2048][Lc]  lW logmdct buffer (lastmdct)
+    float *tblock;                  // [256][Lc]   temporal masking buffer (tempmdct)
+    float *lowcomp;                 // [Lc]        lownoise_compand_level
+    float *g_ampmax;                // [S]         psy_g_look->ampmax
+    float *vbi_ampmax;              // [S]         vorbis_block_internal.ampmax of the stream's block
+    int *lW_block_mode, *lW_no, *impadnum;  // [S]
+};
+
+struct vbm_batch {
+    const vbm_setup *setup;         // device copy
+    vbm_stream_state st;
+    int block_mode;                 // uniform for the batch
+    int W;                          // block_mode >> 1
+    int N, n;                       // block size, n = N/2
+    int ch;
+    int nsb;                        // stream-blocks in this batch
+    int ncb;                        // channel-blocks = nsb*ch
+    int L;                          // ncb rounded up to 64
+    int Ls;                         // nsb rounded up to 64
+    const int *stream_id;           // [nsb] stream index of every stream-block
+    const uint8_t *wflags;          // [nsb] bit0 = lW, bit1 = nW (vb->lW, vb->nW)
+    // block-major transform interface
+    const float *pcm;               // [ncb][N] un-windowed block PCM
+    float *mdct_bm;                 // [ncb][n]
+    float *logfft_bm;               // [ncb][n]
+    float *local_ampmax;            // [ncb]
+    uint8_t *wflags_cb;             // [ncb] wflags replicated per channel-block
+    // bin-major stage buffers, leading dimension L
+    float *mdctT, *logfftT, *logmdctT, *noiseT, *toneT, *logmaskT, *epeakT, *workT;
+    float *npeakT;                  // [n/partition][L]
+    float *sumT;                    // [5][n][L]  N, X, XX, Y, XY of bark_noise_hybridmp
+    float *seedT;                   // [total_octave_lines][L]
+    float *ampstackT;               // [total_octave_lines][L]
+    int *posstackT;                 // [total_octave_lines][L]
+    float *poste;                   // [L]
+    float *global_ampmax;           // [Ls]
+    int *postT;                     // [VIF_POSIT+2][L]  floor posts (fit, then quantised by encode)
+    int *post_valid;                // [L]
+    int *floor_outT;                // [VIF_POSIT+2][L]  wrapped deviations to be entropy coded
+    int *iworkT;                    // [n][L]  ilogmask, then quantised residue
+    int *nonzero;                   // [L]
+    // stream-block lanes (leading dimension Ls)
+    int *partwordT;                 // [max partvals][Ls * max bundle]
+    int *workvqT;                   // [ch*n][Ls]  interleaved residue vector of res2 (lib/res0.c:781-787)
+    uint8_t *packetT;               // [max_packet_bytes][Ls]  byte-major packet buffers
+    int *packet_bytes;              // [Ls]
+    int max_packet_bytes;
+};
+
+#ifdef __HIPCC__
+// lib/scales.h:43-51
+__device__ __forceinline__ float vbm_todB(float x)
+{
+    uint32_t i = __float_as_uint(x) & 0x7fffffffu;
+    return (float)((float)i * 7.17711438e-7f - 764.6161886f);
+}
+// lib/scales.h:32-40
+__device__ __forceinline__ float vbm_unitnorm(float x)
+{
+    return __uint_as_float((__float_as_uint(x) & 0x80000000u) | 0x3f800000u);
+}
+#endif

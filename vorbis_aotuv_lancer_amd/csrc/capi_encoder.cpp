@@ -1,0 +1,302 @@
+// Batched encoder object: per-stream carried state + batch workspace on the device, and the
+// per-block pipeline (include/vorbis_mi355x.h, "batched analysis").
+//
+// One call to vbm_analysis_batch() is the batched equivalent of
+//     vorbis_analysis(vb, NULL); vorbis_bitrate_addblock(vb); vorbis_bitrate_flushpacket(vd, &op)
+// (reference lib/analysis.c:29-63, lib/bitrate.c:88-96, :229-252, VBR) for `nsb` blocks of the same
+// block type, one per stream.  Kernel order = mapping0_forward (lib/mapping0.c:738-1322).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "vorbis_mi355x.h"
+#include "setup_host.h"
+#include "batch.h"
+#include "kernels.h"
+#include "mdct_kernel.h"
+#include "vbm_internal.h"
+
+extern "C" int vbm_launch_spread_flags(const vbm_batch *b, hipStream_t st);
+vbm_setup_host *vbm_setup_handle_host(vbm_setup_handle *h);
+
+struct vbm_encoder {
+    vbm_setup_host *H;
+    const vbm_setup *hs;     // host view
+    int S, ch, cap;          // streams, channels, max stream-blocks per batch
+    int L, Ls;               // leading dimensions for `cap`
+    int max_packet_bytes;
+    int max_oct, max_partvals;
+    std::vector<void *> allocs;
+    vbm_batch b;             // template with all workspace pointers set (device pointers)
+    int *d_stream_id;
+    uint8_t *d_wflags;
+    // last batch (for vbm_encoder_fetch)
+    int last_nsb, last_mode;
+};
+
+static int round64(int x) { return (x + 63) & ~63; }
+
+template <typename T>
+static int dalloc(vbm_encoder *e, T **p, size_t count, bool zero = true)
+{
+    hipError_t err = hipMalloc((void **)p, count * sizeof(T) + 256);
+    if (err != hipSuccess) return vbm_set_hip_error(err, "hipMalloc(encoder workspace)");
+    e->allocs.push_back(*p);
+    if (zero) {
+        err = hipMemset(*p, 0, count * sizeof(T) + 256);
+        if (err != hipSuccess) return vbm_set_hip_error(err, "hipMemset");
+    }
+    return 0;
+}
+
+extern "C" void vbm_encoder_destroy(vbm_encoder *e)
+{
+    if (!e) return;
+    for (void *p : e->allocs) (void)hipFree(p);
+    delete e;
+}
+
+extern "C" int vbm_encoder_create(vbm_encoder **out, vbm_setup_handle *setup, int nstreams, int max_batch)
+{
+    if (!out || !setup || nstreams <= 0 || max_batch <= 0) return VBM_EINVAL;
+    *out = nullptr;
+    int ndev = vbm_device_count();
+    if (ndev < 0) return ndev;
+    if (ndev == 0) {
+        g_vbm_err = "no HIP device: the MI355X path has no CPU fallback";
+        return VBM_ENODEV;
+    }
+    vbm_encoder *e = new vbm_encoder();
+    e->H = vbm_setup_handle_host(setup);
+    int rc = vbm_setup_host_upload(e->H);
+    if (rc) { delete e; return rc; }
+    e->hs = vbm_setup_host_view(e->H);
+    const vbm_setup *s = e->hs;
+    e->S = nstreams;
+    e->ch = s->channels;
+    e->cap = max_batch;
+    e->L = round64(max_batch * e->ch);
+    e->Ls = round64(max_batch);
+    e->max_packet_bytes = 4096 * ((e->ch + 1) / 2);   // generous: q10 stereo long blocks stay < 3 KB
+    e->max_oct = 0;
+    for (int i = 0; i < s->psys; i++)
+        if (s->psy[i].total_octave_lines > e->max_oct) e->max_oct = s->psy[i].total_octave_lines;
+    if (e->max_oct < 256) e->max_oct = 256;
+    e->max_partvals = 1;
+    for (int i = 0; i < s->residues; i++) {
+        int pv = (s->residue[i].end - s->residue[i].begin) / s->residue[i].grouping;
+        if (pv > e->max_partvals) e->max_partvals = pv;
+    }
+    e->last_nsb = 0;
+    e->last_mode = -1;
+
+    const int Nmax = s->blocksizes[1], nmax = Nmax / 2;
+    const size_t L = e->L, Ls = e->Ls;
+    vbm_batch &b = e->b;
+    memset(&b, 0, sizeof(b));
+    b.setup = vbm_setup_device(e->H);
+    b.ch = e->ch;
+    b.max_packet_bytes = e->max_packet_bytes;
+#define A(field, type, count) do { type *p_; rc = dalloc<type>(e, &p_, (count)); if (rc) { vbm_encoder_destroy(e); return rc; } field = p_; } while (0)
+    // stream state (lib/codec_internal.h:85-92); -9999 ampmax as vorbis_block_init / _vp_global_look set it
+    b.st.S = nstreams;
+    b.st.ch = e->ch;
+    b.st.Lc = round64(nstreams * e->ch);
+    A(b.st.mblock, float, (size_t)2048 * b.st.Lc);
+    A(b.st.tblock, float, (size_t)256 * b.st.Lc);
+    A(b.st.lowcomp, float, (size_t)b.st.Lc);
+    A(b.st.g_ampmax, float, (size_t)nstreams);
+    A(b.st.vbi_ampmax, float, (size_t)nstreams);
+    A(b.st.lW_block_mode, int, (size_t)nstreams);
+    A(b.st.lW_no, int, (size_t)nstreams);
+    A(b.st.impadnum, int, (size_t)nstreams);
+    {
+        std::vector<float> init(nstreams, -9999.f);
+        (void)hipMemcpy(b.st.g_ampmax, init.data(), nstreams * sizeof(float), hipMemcpyHostToDevice);
+        (void)hipMemcpy(b.st.vbi_ampmax, init.data(), nstreams * sizeof(float), hipMemcpyHostToDevice);
+    }
+    A(e->d_stream_id, int, Ls);
+    A(e->d_wflags, uint8_t, Ls);
+    A(b.mdct_bm, float, L * nmax);
+    A(b.logfft_bm, float, L * nmax);
+    A(b.local_ampmax, float, L);
+    A(b.wflags_cb, uint8_t, L);
+    A(b.mdctT, float, L * nmax);
+    A(b.logfftT, float, L * nmax);
+    A(b.logmdctT, float, L * nmax);
+    A(b.noiseT, float, L * nmax);
+    A(b.toneT, float, L * nmax);
+    A(b.logmaskT, float, L * nmax);
+    A(b.epeakT, float, L * nmax);
+    A(b.workT, float, L * nmax);
+    A(b.npeakT, float, L * (nmax / 8 + 1));
+    A(b.sumT, float, L * nmax * 5);
+    A(b.seedT, float, L * e->max_oct);
+    A(b.ampstackT, float, L * e->max_oct);
+    A(b.posstackT, int, L * e->max_oct);
+    A(b.poste, float, L);
+    A(b.global_ampmax, float, Ls);
+    A(b.postT, int, L * (VBM_VIF_POSIT + 2));
+    A(b.post_valid, int, L);
+    A(b.floor_outT, int, L * (VBM_VIF_POSIT + 2));
+    A(b.iworkT, int, L * nmax);
+    A(b.nonzero, int, L);
+    A(b.partwordT, int, Ls * (size_t)e->max_partvals * e->ch);
+    A(b.workvqT, int, Ls * (size_t)nmax * e->ch);
+    A(b.packetT, uint8_t, Ls * (size_t)e->max_packet_bytes);
+    A(b.packet_bytes, int, Ls);
+#undef A
+    b.stream_id = e->d_stream_id;
+    b.wflags = e->d_wflags;
+    *out = e;
+    return VBM_OK;
+}
+
+extern "C" int vbm_encoder_max_packet_bytes(const vbm_encoder *e) { return e ? e->max_packet_bytes : VBM_EINVAL; }
+
+extern "C" int vbm_encoder_reset(vbm_encoder *e)
+{
+    if (!e) return VBM_EINVAL;
+    vbm_stream_state &st = e->b.st;
+    (void)hipMemset(st.mblock, 0, (size_t)2048 * st.Lc * sizeof(float));
+    (void)hipMemset(st.tblock, 0, (size_t)256 * st.Lc * sizeof(float));
+    (void)hipMemset(st.lowcomp, 0, (size_t)st.Lc * sizeof(float));
+    (void)hipMemset(st.lW_block_mode, 0, e->S * sizeof(int));
+    (void)hipMemset(st.lW_no, 0, e->S * sizeof(int));
+    (void)hipMemset(st.impadnum, 0, e->S * sizeof(int));
+    std::vector<float> init(e->S, -9999.f);
+    (void)hipMemcpy(st.g_ampmax, init.data(), e->S * sizeof(float), hipMemcpyHostToDevice);
+    (void)hipMemcpy(st.vbi_ampmax, init.data(), e->S * sizeof(float), hipMemcpyHostToDevice);
+    return VBM_OK;
+}
+
+static void configure(vbm_encoder *e, vbm_batch &b, int block_mode, int nsb, const float *d_pcm)
+{
+    b = e->b;
+    const vbm_setup *s = e->hs;
+    b.block_mode = block_mode;
+    b.W = block_mode >> 1;
+    b.N = s->blocksizes[b.W];
+    b.n = b.N / 2;
+    b.nsb = nsb;
+    b.ncb = nsb * e->ch;
+    b.L = e->L;      // fixed leading dimensions: buffers were sized for `cap`
+    b.Ls = e->Ls;
+    b.pcm = d_pcm;
+}
+
+extern "C" int vbm_analysis_batch(vbm_encoder *e, int block_mode, int nsb, const int *stream_ids,
+                                  const uint8_t *wflags, const float *d_pcm, uint8_t *d_packets,
+                                  int *d_packet_bytes, void *stream)
+{
+    if (!e || block_mode < 0 || block_mode > 3 || nsb < 0 || nsb > e->cap) return VBM_EINVAL;
+    if (nsb == 0) return VBM_OK;
+    if (!stream_ids || !wflags || !d_pcm) return VBM_EINVAL;
+    if ((uintptr_t)d_pcm & 15) return VBM_EINVAL;
+    const vbm_setup *s = e->hs;
+    if (s->modes < 2 && (block_mode >> 1)) return VBM_EINVAL;
+    for (int i = 0; i < nsb; i++)
+        if (stream_ids[i] < 0 || stream_ids[i] >= e->S) return VBM_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t err;
+    if ((err = hipMemcpyAsync(e->d_stream_id, stream_ids, nsb * sizeof(int), hipMemcpyHostToDevice, st)) != hipSuccess)
+        return vbm_set_hip_error(err, "hipMemcpyAsync(stream_ids)");
+    if ((err = hipMemcpyAsync(e->d_wflags, wflags, nsb, hipMemcpyHostToDevice, st)) != hipSuccess)
+        return vbm_set_hip_error(err, "hipMemcpyAsync(wflags)");
+
+    vbm_batch b;
+    configure(e, b, block_mode, nsb, d_pcm);
+    e->last_nsb = nsb;
+    e->last_mode = block_mode;
+
+    int W = b.W;
+    int rc = 0;
+#define RUN(x) do { rc = (x); if (rc) { g_vbm_err = std::string("launch failed: ") + #x; return VBM_EHIP; } } while (0)
+    RUN(vbm_launch_spread_flags(&b, st));
+    // loop A: window + MDCT, window + FFT + log spectrum (wave per block)
+    RUN(vbm_launch_window_mdct(b.pcm, b.mdct_bm, W ? b.wflags_cb : nullptr, vbm_setup_device_ptrs(e->H)->mdct_trig[W],
+                               vbm_setup_device_ptrs(e->H)->window[W], vbm_setup_device_ptrs(e->H)->window[0], b.N,
+                               s->blocksizes[0], 1, b.ncb, 0, st));
+    RUN(vbm_launch_window_fft_log(b.pcm, b.logfft_bm, b.local_ampmax, W ? b.wflags_cb : nullptr,
+                                  vbm_setup_device_ptrs(e->H)->fft_wa[W], vbm_setup_device_ptrs(e->H)->window[W],
+                                  vbm_setup_device_ptrs(e->H)->window[0], b.N, s->blocksizes[0], b.ncb, st));
+    RUN(vbm_launch_transpose_in(&b, st));
+    // loop B: psychoacoustics + floor fit (lane per channel-block)
+    RUN(vbm_launch_prologue(&b, st));
+    RUN(vbm_launch_noisemask(&b, st));
+    RUN(vbm_launch_tonemask(&b, st));
+    RUN(vbm_launch_mix(&b, st));
+    RUN(vbm_launch_floor_fit(&b, st));
+    // loop C: floor encode, couple/quantise, residue + packet assembly
+    RUN(vbm_launch_floor_encode(&b, st));
+    RUN(vbm_launch_couple_quantize(&b, st));
+    RUN(vbm_launch_pack(&b, st));
+    if (d_packets)
+        RUN(vbm_launch_untranspose_u8(b.packetT, d_packets, e->max_packet_bytes, b.Ls, nsb, st));
+    if (d_packet_bytes) {
+        if ((err = hipMemcpyAsync(d_packet_bytes, b.packet_bytes, nsb * sizeof(int), hipMemcpyDeviceToDevice, st)) != hipSuccess)
+            return vbm_set_hip_error(err, "hipMemcpyAsync(packet_bytes)");
+    }
+#undef RUN
+    return VBM_OK;
+}
+
+// Stage intermediates of the LAST batch, converted to block-major rows, for parity tests.
+extern "C" int vbm_encoder_fetch(vbm_encoder *e, const char *name, void *d_out, long *rows_out, char *kind,
+                                 void *stream)
+{
+    if (!e || !name || e->last_nsb <= 0) return VBM_EINVAL;
+    vbm_batch b;
+    configure(e, b, e->last_mode, e->last_nsb, nullptr);
+    hipStream_t st = (hipStream_t)stream;
+    const vbm_setup *s = e->hs;
+    const vbm_psy &p = s->psy[b.block_mode];
+    const int partition = p.normal_p ? p.normal_partition : 16;
+    struct Ent { const char *name; const void *ptr; int rows; char kind; int lanes; };
+    const Ent table[] = {
+        {"mdct_raw", b.mdct_bm, -1, 'f', b.ncb},        // block-major already
+        {"logfft", b.logfft_bm, -1, 'f', b.ncb},
+        {"mdct", b.mdctT, b.n, 'f', b.ncb},             // after M1 rescale
+        {"logmdct", b.logmdctT, b.n, 'f', b.ncb},
+        {"noise", b.noiseT, b.n, 'f', b.ncb},
+        {"tone", b.toneT, b.n, 'f', b.ncb},
+        {"logmask", b.logmaskT, b.n, 'f', b.ncb},
+        {"epeak", b.epeakT, b.n, 'f', b.ncb},
+        {"npeak", b.npeakT, b.n / partition, 'f', b.ncb},
+        {"post", b.postT, VBM_VIF_POSIT + 2, 'i', b.ncb},
+        {"floor_out", b.floor_outT, VBM_VIF_POSIT + 2, 'i', b.ncb},
+        {"residue", b.iworkT, b.n, 'i', b.ncb},
+    };
+    for (const Ent &t : table) {
+        if (strcmp(t.name, name)) continue;
+        if (rows_out) *rows_out = t.rows < 0 ? b.n : t.rows;
+        if (kind) *kind = t.kind;
+        if (!d_out) return VBM_OK;
+        if (t.rows < 0) {
+            hipError_t err = hipMemcpyAsync(d_out, t.ptr, (size_t)b.ncb * b.n * 4, hipMemcpyDeviceToDevice, st);
+            return err == hipSuccess ? VBM_OK : vbm_set_hip_error(err, "hipMemcpyAsync(fetch)");
+        }
+        int rc = (t.kind == 'f')
+                     ? vbm_launch_untranspose_f32((const float *)t.ptr, (float *)d_out, t.rows, b.L, t.lanes, st)
+                     : vbm_launch_untranspose_i32((const int *)t.ptr, (int *)d_out, t.rows, b.L, t.lanes, st);
+        return rc ? VBM_EHIP : VBM_OK;
+    }
+    struct Vec { const char *name; const void *ptr; char kind; int count; };
+    const Vec vecs[] = {
+        {"local_ampmax", b.local_ampmax, 'f', b.ncb}, {"global_ampmax", b.global_ampmax, 'f', b.nsb},
+        {"post_valid", b.post_valid, 'i', b.ncb},     {"nonzero", b.nonzero, 'i', b.ncb},
+        {"poste", b.poste, 'f', b.ncb},               {"packet_bytes", b.packet_bytes, 'i', b.nsb},
+    };
+    for (const Vec &t : vecs) {
+        if (strcmp(t.name, name)) continue;
+        if (rows_out) *rows_out = 1;
+        if (kind) *kind = t.kind;
+        if (!d_out) return VBM_OK;
+        hipError_t err = hipMemcpyAsync(d_out, t.ptr, (size_t)t.count * 4, hipMemcpyDeviceToDevice, st);
+        return err == hipSuccess ? VBM_OK : vbm_set_hip_error(err, "hipMemcpyAsync(fetch)");
+    }
+    g_vbm_err = std::string("unknown intermediate: ") + name;
+    return VBM_EINVAL;
+}

@@ -1,0 +1,453 @@
+// Floor-1 fit and encode for gfx950 — one lane per channel-block (batch.h layout).
+//
+//   k_floor_fit     floor1_fit (reference lib/floor1.c:597-750): accumulate_fit :427-475 (integer
+//                   sums per post segment), fit_line :477-535 (double least squares, rint),
+//                   inspect_error :537-586, greedy splitting :646-719, post_Y / render_point
+//   k_floor_encode  value part of floor1_encode (lib/floor1.c:774-852, 944-973): quantise posts
+//                   by `mult`, predict / wrap the deviations, render the integer floor curve
+//                   (render_line0 :397-424) into ilogmask.  The entropy coding of the wrapped
+//                   deviations (:856-942) happens in the packet kernel, in channel order.
+// Segment bounds, neighbour tables and sort order come from the floor look and are the same
+// in every lane; only the greedy split decisions diverge.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "batch.h"
+#include "kernels.h"
+
+#define T(buf, i) (buf)[(size_t)(i) * L + lane]
+
+namespace {
+
+struct lsfit_acc {
+    int x0, x1;
+    int xa, ya, x2a, y2a, xya, an;
+    int xb, yb, x2b, y2b, xyb, bn;
+};
+
+__device__ __forceinline__ int render_point(int x0, int x1, int y0, int y1, int x)
+{
+    y0 &= 0x7fff;
+    y1 &= 0x7fff;
+    int dy = y1 - y0;
+    int adx = x1 - x0;
+    int ady = abs(dy);
+    int err = ady * (x - x0);
+    int off = err / adx;
+    if (dy < 0) return (y0 - off);
+    return (y0 + off);
+}
+
+// lib/floor1.c:294 (scalar): int i = *x*7.3142857f+1023.5f
+__device__ __forceinline__ int dBquant(float x)
+{
+    int i = (int)(x * 7.3142857f + 1023.5f);
+    if (i > 1023) return (1023);
+    if (i < 0) return (0);
+    return i;
+}
+
+__device__ int fit_line(const lsfit_acc *a, int fits, int *y0, int *y1, const vbm_floor *info)
+{
+    double xb = 0, yb = 0, x2b = 0, y2b = 0, xyb = 0, bn = 0;
+    int i;
+    int x0 = a[0].x0;
+    int x1 = a[fits - 1].x1;
+
+    for (i = 0; i < fits; i++) {
+        double weight = (double)((float)(a[i].bn + a[i].an) * info->twofitweight / (float)(a[i].an + 1)) + 1.;
+
+        xb += a[i].xb + a[i].xa * weight;
+        yb += a[i].yb + a[i].ya * weight;
+        x2b += a[i].x2b + a[i].x2a * weight;
+        y2b += a[i].y2b + a[i].y2a * weight;
+        xyb += a[i].xyb + a[i].xya * weight;
+        bn += a[i].bn + a[i].an * weight;
+    }
+
+    if (*y0 >= 0) {
+        xb += x0;
+        yb += *y0;
+        x2b += x0 * x0;
+        y2b += *y0 * *y0;
+        xyb += *y0 * x0;
+        bn++;
+    }
+
+    if (*y1 >= 0) {
+        xb += x1;
+        yb += *y1;
+        x2b += x1 * x1;
+        y2b += *y1 * *y1;
+        xyb += *y1 * x1;
+        bn++;
+    }
+
+    {
+        double denom = (bn * x2b - xb * xb);
+
+        if (denom > 0.) {
+            double aa = (yb * x2b - xyb * xb) / denom;
+            double bb = (bn * xyb - xb * yb) / denom;
+            *y0 = (int)rint(aa + bb * x0);
+            *y1 = (int)rint(aa + bb * x1);
+
+            if (*y0 > 1023) *y0 = 1023;
+            if (*y1 > 1023) *y1 = 1023;
+            if (*y0 < 0) *y0 = 0;
+            if (*y1 < 0) *y1 = 0;
+            return 0;
+        } else {
+            *y0 = 0;
+            *y1 = 0;
+            return 1;
+        }
+    }
+}
+
+__device__ __forceinline__ int post_Y(const int *A, const int *B, int pos)
+{
+    if (A[pos] < 0) return B[pos];
+    if (B[pos] < 0) return A[pos];
+    return (A[pos] + B[pos]) >> 1;
+}
+
+__global__ void k_floor_fit(vbm_batch b)
+{
+    const int lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= b.ncb) return;
+    const int L = b.L;
+    const vbm_setup *s = b.setup;
+    const int c = lane % b.ch;
+    const vbm_map *map = &s->map[b.W];
+    const vbm_floor *look = &s->floor[map->floorsubmap[map->chmuxlist[c]]];
+    const vbm_floor *info = look;
+    const float *logmdct = b.logmdctT, *logmask = b.logmaskT;
+    const int n = look->n;
+    const int posts = look->posts;
+    int i, j;
+    int nonzero = 0;
+
+    lsfit_acc fits[VBM_VIF_POSIT + 1];
+    int fit_valueA[VBM_VIF_POSIT + 2];
+    int fit_valueB[VBM_VIF_POSIT + 2];
+    int loneighbor[VBM_VIF_POSIT + 2];
+    int hineighbor[VBM_VIF_POSIT + 2];
+    int memo[VBM_VIF_POSIT + 2];
+
+    for (i = 0; i < posts; i++) {
+        fit_valueA[i] = -200;
+        fit_valueB[i] = -200;
+        loneighbor[i] = 0;
+        hineighbor[i] = 1;
+        memo[i] = -1;
+    }
+
+    // accumulate_fit over every minimal division (lib/floor1.c:625-628)
+    for (int seg = 0; seg < posts - 1; seg++) {
+        int x0 = look->sorted_index[seg], x1 = look->sorted_index[seg + 1];
+        int xa = 0, ya = 0, x2a = 0, y2a = 0, xya = 0, na = 0, xb = 0, yb = 0, x2b = 0, y2b = 0, xyb = 0, nb = 0;
+        lsfit_acc *a = &fits[seg];
+        a->x0 = x0;
+        a->x1 = x1;
+        if (x1 >= n) x1 = n - 1;
+        for (i = x0; i <= x1; i++) {
+            float fl = T(logmask, i);
+            int quantized = dBquant(fl);
+            if (quantized) {
+                if (T(logmdct, i) + info->twofitatten >= fl) {
+                    xa += i; ya += quantized; x2a += i * i; y2a += quantized * quantized; xya += i * quantized; na++;
+                } else {
+                    xb += i; yb += quantized; x2b += i * i; y2b += quantized * quantized; xyb += i * quantized; nb++;
+                }
+            }
+        }
+        a->xa = xa; a->ya = ya; a->x2a = x2a; a->y2a = y2a; a->xya = xya; a->an = na;
+        a->xb = xb; a->yb = yb; a->x2b = x2b; a->y2b = y2b; a->xyb = xyb; a->bn = nb;
+        nonzero += na;
+    }
+
+    if (!nonzero) {
+        b.post_valid[lane] = 0;
+        return;
+    }
+
+    {
+        int y0 = -200;
+        int y1 = -200;
+        fit_line(fits, posts - 1, &y0, &y1, info);
+
+        fit_valueA[0] = y0;
+        fit_valueB[0] = y0;
+        fit_valueB[1] = y1;
+        fit_valueA[1] = y1;
+
+        for (i = 2; i < posts; i++) {
+            int sortpos = look->reverse_index[i];
+            int ln = loneighbor[sortpos];
+            int hn = hineighbor[sortpos];
+
+            if (memo[ln] != hn) {
+                int lsortpos = look->reverse_index[ln];
+                int hsortpos = look->reverse_index[hn];
+                memo[ln] = hn;
+                {
+                    int lx = info->postlist[ln];
+                    int hx = info->postlist[hn];
+                    int ly = post_Y(fit_valueA, fit_valueB, ln);
+                    int hy = post_Y(fit_valueA, fit_valueB, hn);
+                    // (the reference exit(1)s on ly == -1 || hy == -1, which cannot occur: values are
+                    //  -200 or >= 0)
+
+                    // inspect_error (lib/floor1.c:537-586)
+                    int split;
+                    {
+                        int dy = hy - ly;
+                        int adx = hx - lx;
+                        int ady = abs(dy);
+                        int base = dy / adx;
+                        int sy = (dy < 0 ? base - 1 : base + 1);
+                        int x = lx;
+                        int y = ly;
+                        int err = 0;
+                        int val = dBquant(T(logmask, x));
+                        int mse = 0;
+                        int cnt = 0;
+                        split = -1;
+
+                        ady -= abs(base * adx);
+
+                        mse = (y - val);
+                        mse *= mse;
+                        cnt++;
+                        if (T(logmdct, x) + info->twofitatten >= T(logmask, x)) {
+                            if (y + info->maxover < val) split = 1;
+                            if (y - info->maxunder > val) split = 1;
+                        }
+                        if (split < 0) {
+                            while (++x < hx) {
+                                err = err + ady;
+                                if (err >= adx) {
+                                    err -= adx;
+                                    y += sy;
+                                } else {
+                                    y += base;
+                                }
+                                float mk = T(logmask, x);
+                                val = dBquant(mk);
+                                mse += ((y - val) * (y - val));
+                                cnt++;
+                                if (T(logmdct, x) + info->twofitatten >= mk) {
+                                    if (val) {
+                                        if (y + info->maxover < val) { split = 1; break; }
+                                        if (y - info->maxunder > val) { split = 1; break; }
+                                    }
+                                }
+                            }
+                        }
+                        if (split < 0) {
+                            if (info->maxover * info->maxover / cnt > info->maxerr) split = 0;
+                            else if (info->maxunder * info->maxunder / cnt > info->maxerr) split = 0;
+                            else if (mse / cnt > info->maxerr) split = 1;
+                            else split = 0;
+                        }
+                    }
+
+                    if (split) {
+                        int ly0 = -200, ly1 = -200, hy0 = -200, hy1 = -200;
+                        int ret0 = fit_line(fits + lsortpos, sortpos - lsortpos, &ly0, &ly1, info);
+                        int ret1 = fit_line(fits + sortpos, hsortpos - sortpos, &hy0, &hy1, info);
+
+                        if (ret0) {
+                            ly0 = ly;
+                            ly1 = hy0;
+                        }
+                        if (ret1) {
+                            hy0 = ly1;
+                            hy1 = hy;
+                        }
+
+                        if (ret0 && ret1) {
+                            fit_valueA[i] = -200;
+                            fit_valueB[i] = -200;
+                        } else {
+                            fit_valueB[ln] = ly0;
+                            if (ln == 0) fit_valueA[ln] = ly0;
+                            fit_valueA[i] = ly1;
+                            fit_valueB[i] = hy0;
+                            fit_valueA[hn] = hy1;
+                            if (hn == 1) fit_valueB[hn] = hy1;
+
+                            if (ly1 >= 0 || hy0 >= 0) {
+                                for (j = sortpos - 1; j >= 0; j--)
+                                    if (hineighbor[j] == hn) hineighbor[j] = i;
+                                    else break;
+                                for (j = sortpos + 1; j < posts; j++)
+                                    if (loneighbor[j] == ln) loneighbor[j] = i;
+                                    else break;
+                            }
+                        }
+                    } else {
+                        fit_valueA[i] = -200;
+                        fit_valueB[i] = -200;
+                    }
+                }
+            }
+        }
+
+        int *output = b.postT;
+        int o0 = post_Y(fit_valueA, fit_valueB, 0);
+        int o1 = post_Y(fit_valueA, fit_valueB, 1);
+        T(output, 0) = o0;
+        T(output, 1) = o1;
+
+        for (i = 2; i < posts; i++) {
+            int ln = look->loneighbor[i - 2];
+            int hn = look->hineighbor[i - 2];
+            int x0 = info->postlist[ln];
+            int x1 = info->postlist[hn];
+            int y0 = T(output, ln);
+            int y1 = T(output, hn);
+
+            int predicted = render_point(x0, x1, y0, y1, info->postlist[i]);
+            int vx = post_Y(fit_valueA, fit_valueB, i);
+
+            if (vx >= 0 && predicted != vx) {
+                T(output, i) = vx;
+            } else {
+                T(output, i) = predicted | 0x8000;
+            }
+        }
+    }
+    b.post_valid[lane] = 1;
+}
+
+__global__ void k_floor_encode(vbm_batch b)
+{
+    const int lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= b.ncb) return;
+    const int L = b.L;
+    const vbm_setup *s = b.setup;
+    const int c = lane % b.ch;
+    const vbm_map *map = &s->map[b.W];
+    const vbm_floor *look = &s->floor[map->floorsubmap[map->chmuxlist[c]]];
+    const vbm_floor *info = look;
+    const int posts = look->posts;
+    const int n = b.n;
+    int *post = b.postT, *out = b.floor_outT, *ilogmask = b.iworkT;
+    int i, j;
+
+    if (!b.post_valid[lane]) {
+        for (i = 0; i < n; i++) T(ilogmask, i) = 0;
+        b.nonzero[lane] = 0;
+        return;
+    }
+
+    for (i = 0; i < posts; i++) {
+        int pv = T(post, i);
+        int val = pv & 0x7fff;
+        switch (info->mult) {
+        case 1: val >>= 2; break;
+        case 2: val >>= 3; break;
+        case 3: val /= 12; break;
+        case 4: val >>= 4; break;
+        }
+        T(post, i) = val | (pv & 0x8000);
+    }
+
+    T(out, 0) = T(post, 0);
+    T(out, 1) = T(post, 1);
+
+    for (i = 2; i < posts; i++) {
+        int ln = look->loneighbor[i - 2];
+        int hn = look->hineighbor[i - 2];
+        int x0 = info->postlist[ln];
+        int x1 = info->postlist[hn];
+        int y0 = T(post, ln);
+        int y1 = T(post, hn);
+        int pi = T(post, i);
+
+        int predicted = render_point(x0, x1, y0, y1, info->postlist[i]);
+
+        if ((pi & 0x8000) || (predicted == pi)) {
+            T(post, i) = predicted | 0x8000;
+            T(out, i) = 0;
+        } else {
+            int headroom = (look->quant_q - predicted < predicted ? look->quant_q - predicted : predicted);
+            int val = pi - predicted;
+
+            if (val < 0)
+                if (val < -headroom) val = headroom - val - 1;
+                else val = -1 - (val << 1);
+            else if (val >= headroom) val = val + headroom;
+            else val <<= 1;
+
+            T(out, i) = val;
+            T(post, ln) &= 0x7fff;
+            T(post, hn) &= 0x7fff;
+        }
+    }
+
+    // render the quantised floor exactly as the decoder will (lib/floor1.c:944-967)
+    {
+        int hx = 0;
+        int lx = 0;
+        int ly = T(post, 0) * info->mult;
+
+        for (j = 1; j < posts; j++) {
+            int current = look->forward_index[j];
+            int pc = T(post, current);
+            int hy = pc & 0x7fff;
+            if (hy == pc) {
+                hy *= info->mult;
+                hx = info->postlist[current];
+
+                // render_line0(n, lx, hx, ly, hy, ilogmask)
+                {
+                    int dy = hy - ly;
+                    int adx = hx - lx;
+                    int ady = abs(dy);
+                    int base = dy / adx;
+                    int sy = (dy < 0 ? base - 1 : base + 1);
+                    int x = lx;
+                    int y = ly;
+                    int err = 0;
+                    int nn = n;
+
+                    ady -= abs(base * adx);
+                    if (nn > hx) nn = hx;
+                    if (x < nn) T(ilogmask, x) = y;
+                    while (++x < nn) {
+                        err = err + ady;
+                        if (err >= adx) {
+                            err -= adx;
+                            y += sy;
+                        } else {
+                            y += base;
+                        }
+                        T(ilogmask, x) = y;
+                    }
+                }
+
+                lx = hx;
+                ly = hy;
+            }
+        }
+        for (j = hx; j < n; j++) T(ilogmask, j) = ly;
+    }
+    b.nonzero[lane] = 1;
+}
+
+}  // namespace
+
+static inline dim3 grid_for(int lanes) { return dim3((unsigned)((lanes + 63) / 64)); }
+
+extern "C" int vbm_launch_floor_fit(const vbm_batch *b, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_floor_fit, grid_for(b->ncb), dim3(64), 0, st, *b);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+extern "C" int vbm_launch_floor_encode(const vbm_batch *b, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_floor_encode, grid_for(b->ncb), dim3(64), 0, st, *b);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}

@@ -1,0 +1,19 @@
+// internal: launchers of the batch kernels (each returns 0, or -2 on a launch error)
+#pragma once
+#include <hip/hip_runtime.h>
+#include "batch.h"
+
+extern "C" {
+int vbm_launch_transpose_in(const vbm_batch *b, hipStream_t st);   // mdct_bm/logfft_bm -> mdctT/logfftT
+int vbm_launch_prologue(const vbm_batch *b, hipStream_t st);
+int vbm_launch_noisemask(const vbm_batch *b, hipStream_t st);
+int vbm_launch_tonemask(const vbm_batch *b, hipStream_t st);
+int vbm_launch_mix(const vbm_batch *b, hipStream_t st);
+int vbm_launch_floor_fit(const vbm_batch *b, hipStream_t st);
+int vbm_launch_floor_encode(const vbm_batch *b, hipStream_t st);
+int vbm_launch_couple_quantize(const vbm_batch *b, hipStream_t st);
+int vbm_launch_pack(const vbm_batch *b, hipStream_t st);
+int vbm_launch_untranspose_f32(const float *srcT, float *dst_bm, int rows, int L, int ncb, hipStream_t st);
+int vbm_launch_untranspose_i32(const int *srcT, int *dst_bm, int rows, int L, int ncb, hipStream_t st);
+int vbm_launch_untranspose_u8(const uint8_t *srcT, uint8_t *dst_bm, int rows, int L, int ncb, hipStream_t st);
+}

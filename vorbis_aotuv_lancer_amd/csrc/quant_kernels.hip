@@ -1,0 +1,427 @@
+// Channel coupling + quantisation + noise normalisation for gfx950 — one lane per stream-block.
+//
+//   k_couple_quantize   _vp_couple_quantize_normalize (reference lib/psy.c:4858-5142) with
+//                       flag_lossless :4584-4624, noise_normalize :4732-4854 (ssort :4709),
+//                       lossless_coupling(f) :4626-4658, min_indemnity_dipole_hypot :4660-4673,
+//                       VBR blob PACKETBLOBS/2.
+// Partitions are walked in order inside the lane because aoTuV M6 carries `side_resdef` from
+// one partition to the next (:5032-5034) and `residue_def` is an order-bound float sum; the
+// per-partition scratch (raw/quant/floor/res/flag, <= 8 ch x 32 bins) lives in private memory.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "batch.h"
+#include "kernels.h"
+
+#define PART_MAX 32
+#define existe(x, y) (x < -y || x >= y)
+#define refer_phase(a, b) ((a > 0. && b < 0.) || (b > 0. && a < 0.))
+#define VMIN(x, y) ((x) > (y) ? (y) : (x))
+
+namespace {
+
+__device__ void flag_lossless(int limit, float prepoint, float postpoint, float prepoint_r, float postpoint_r,
+                              float *res, const float *mdct, const float *enpeak, const float *floor, int *flag,
+                              int i, int jn)
+{
+    int j, ps = 0;
+    int pointlimit = limit - i;
+    float point1, point2, bakp1, r;
+    float ps1 = 0.f, ps2 = 0.f;
+
+    if (pointlimit > 0) {
+        point1 = prepoint;
+        point2 = prepoint_r;
+        if ((pointlimit - jn) <= 0) {
+            ps1 = (postpoint - prepoint) / jn;
+            ps2 = (postpoint_r - prepoint_r) / jn;
+            ps = 1;
+        }
+    } else {
+        point1 = postpoint;
+        point2 = postpoint_r;
+    }
+    for (j = 0; j < jn; j++) {
+        if (ps == 1) {
+            point1 += ps1;
+            point2 += ps2;
+        }
+        bakp1 = point1;
+
+        res[j] = mdct[j] / floor[j];
+        r = fabsf(res[j]);
+        point1 -= enpeak[j];
+        if (point1 < prepoint) point1 = prepoint;
+        if (r < point1) {
+            if (r < point2) flag[j] = 0;
+            else flag[j] = -1;
+        } else {
+            flag[j] = 1;
+        }
+        point1 = bakp1;
+    }
+}
+
+__device__ __forceinline__ void lossless_coupling(int *Mag, int *Ang)
+{
+    int A = *Mag;
+    int B = *Ang;
+    if (abs(A) > abs(B)) {
+        *Ang = (A > 0 ? A - B : B - A);
+    } else {
+        *Ang = (B > 0 ? A - B : B - A);
+        *Mag = B;
+    }
+    if (*Ang >= abs(*Mag) * 2) {
+        *Ang = -*Ang;
+        *Mag = -*Mag;
+    }
+}
+
+__device__ __forceinline__ void lossless_couplingf(float *Mag, float *Ang)
+{
+    float A = *Mag;
+    float B = *Ang;
+    if (fabsf(A) > fabsf(B)) {
+        *Ang = (A > 0 ? A - B : B - A);
+    } else {
+        *Ang = (B > 0 ? A - B : B - A);
+        *Mag = B;
+    }
+    if ((double)*Ang >= fabs((double)*Mag) * 2) {
+        *Ang = -*Ang;
+        *Mag = -*Mag;
+    }
+}
+
+__device__ __forceinline__ float min_indemnity_dipole_hypot(const float a, const float b, const float threv)
+{
+    const float thnor = (float)0.94;
+    float a2 = fabsf(a * thnor);
+    float b2 = fabsf(b * thnor);
+    if (a > 0.) {
+        if (b > 0.) return (a2 + b2);
+        if (a > -b) return (a2 - b2 * threv);
+        return -(b2 - a2 * threv);
+    }
+    if (b < 0.) return -(a2 + b2);
+    if (-a > b) return -(a2 - b2 * threv);
+    return (b2 - a2 * threv);
+}
+
+// q / out / r / res / f / flags are this channel's partition scratch; out is strided (bin-major)
+__device__ float noise_normalize(const vbm_psy *p, const int limit, float *r, float *q, const float *f, float *res,
+                                 const int *flags, float acc, const float nepeak, const int i, const int n,
+                                 int *out, const size_t ostride)
+{
+#define OUT(j) out[(size_t)(j) * ostride]
+    int sort[PART_MAX];
+    int j, k, count = 0;
+    int start = (p->normal_p ? p->normal_start - i : n);
+    if ((start > n) || ((double)nepeak < -0.5)) start = n;
+
+    acc = 0.f;
+
+    j = 0;
+    if (!flags) {
+        for (; j < start; j++) OUT(j) = (int)rint((double)res[j]);
+    } else {
+        for (; j < start; j++) {
+            if (flags[j] != 1) {
+                float ve = (float)sqrt((double)(q[j] / f[j]));
+                if (r[j] < 0) {
+                    OUT(j) = (int)-rint((double)ve);
+                    res[j] = -ve;
+                } else {
+                    OUT(j) = (int)rint((double)ve);
+                    res[j] = ve;
+                }
+            }
+        }
+    }
+
+    if (flags) {
+        for (; j < n; j++) {
+            float ve;
+            if (flags[j] != 1) ve = q[j] / f[j];
+            else continue;
+            if (ve < .25f && j >= limit - i) {
+                acc += ve;
+                sort[count++] = j;
+                if (r[j] < 0) res[j] = (float)-sqrt((double)ve);
+                else res[j] = (float)sqrt((double)ve);
+            } else {
+                ve = (float)sqrt((double)ve);
+                int o;
+                if (r[j] < 0) {
+                    o = (int)-rint((double)ve);
+                    res[j] = -ve;
+                } else {
+                    o = (int)rint((double)ve);
+                    res[j] = ve;
+                }
+                OUT(j) = o;
+                q[j] = o * o * f[j];
+            }
+        }
+    } else {
+        for (; j < n; j++) {
+            float ve = res[j] * res[j];
+            if (ve < .25f) {
+                acc += ve;
+                sort[count++] = j;
+            } else {
+                int o = (int)rint((double)res[j]);
+                OUT(j) = o;
+                q[j] = o * o * f[j];
+            }
+        }
+    }
+
+    acc += acc * nepeak * nepeak;
+
+    if (count) {
+        int iacc = ((int)acc) + 1;
+        if (iacc > n) iacc = n;
+        // ssort: partial selection sort, largest q first (lib/psy.c:4709-4726)
+        {
+            int bthresh = iacc;
+            if (count < bthresh) bthresh = count;
+            for (int a = 0; a < bthresh; a++) {
+                int large = a;
+                for (int bb = a + 1; bb < count; bb++)
+                    if (q[sort[large]] < q[sort[bb]]) large = bb;
+                int tmp = sort[a];
+                sort[a] = sort[large];
+                sort[large] = tmp;
+            }
+        }
+        for (k = 0; k < count; k++) {
+            int e = sort[k];
+            if ((double)acc >= p->normal_thresh) {
+                OUT(e) = (int)vbm_unitnorm(r[e]);
+                acc -= 1.f;
+                q[e] = f[e];
+            } else {
+                OUT(e) = 0;
+                q[e] = 0.f;
+            }
+        }
+    }
+    return acc;
+#undef OUT
+}
+
+__global__ void k_couple_quantize(vbm_batch b)
+{
+    const int sb = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sb >= b.nsb) return;
+    const size_t L = b.L;
+    const vbm_setup *s = b.setup;
+    const vbm_psy *p = &s->psy[b.block_mode];
+    const vbm_map *vi = &s->map[b.W];
+    const int ch = b.ch;
+    const int blobno = VBM_PACKETBLOBS / 2;
+    const int n = p->n;
+    const int partition = (p->normal_p ? p->normal_partition : 16);
+    const int limit = s->coupling_pointlimit[p->blockflag][blobno];
+    float prepoint = (float)s->stereo_threshholds[s->coupling_prepointamp[blobno]];
+    float postpoint = (float)s->stereo_threshholds[s->coupling_postpointamp[blobno]];
+    float prepoint_x = (float)s->stereo_threshholds_X[s->coupling_prepointamp[blobno]];
+    float postpoint_x = (float)s->stereo_threshholds_X[s->coupling_postpointamp[blobno]];
+    float prae;
+    const int sliding_lowpass = s->sliding_lowpass[b.W][blobno];
+    int lowpassr;
+    {
+        // lib/mapping0.c:778-781
+        lowpassr = s->block_lowpassr[b.W ? 1 : 0];
+        if (lowpassr % p->normal_partition) lowpassr = (lowpassr / p->normal_partition + 1) * p->normal_partition;
+    }
+
+    float raw[VBM_MAXCH][PART_MAX], quant[VBM_MAXCH][PART_MAX], floor[VBM_MAXCH][PART_MAX], res[VBM_MAXCH][PART_MAX];
+    int flag[VBM_MAXCH][PART_MAX];
+    float mdl[PART_MAX], enp[PART_MAX];
+    int nz[VBM_MAXCH], nonzero[VBM_MAXCH];
+    float acc[VBM_MAXCH + 16];
+    float side_resdef[16];
+    int i, pi;
+
+    // columns of this stream-block's channels in the bin-major arrays
+    const size_t col0 = (size_t)sb * ch;
+#define MD(k, x) b.mdctT[(size_t)(x) * L + col0 + (k)]
+#define EP(k, x) b.epeakT[(size_t)(x) * L + col0 + (k)]
+#define NP(k, x) b.npeakT[(size_t)(x) * L + col0 + (k)]
+#define IW(k, x) b.iworkT[(size_t)(x) * L + col0 + (k)]
+
+    for (i = 0; i < ch; i++) nonzero[i] = b.nonzero[col0 + i];
+    for (i = 0; i < ch + vi->coupling_steps; i++) acc[i] = 0.f;
+
+    if (prepoint_x < prepoint) prepoint_x = prepoint;
+    if (postpoint_x < prepoint) postpoint_x = prepoint;
+
+    for (i = 0; i < vi->coupling_steps; i++) side_resdef[i] = -1.f;
+
+    if (vi->coupling_steps == 1) prae = (float)0.34;
+    else prae = (float)0.825;
+
+    for (i = 0, pi = 0; i < lowpassr; i += partition, pi++) {
+        int k, j, jn = partition > n - i ? n - i : partition;
+        int step, track = 0;
+
+        for (k = 0; k < ch; k++) nz[k] = nonzero[k];
+
+        for (k = 0; k < ch; k++)
+            for (j = 0; j < partition; j++) flag[k][j] = 0;
+
+        for (k = 0; k < ch; k++) {
+            if (nz[k]) {
+                for (j = 0; j < jn; j++) {
+                    floor[k][j] = s->fromdB[IW(k, i + j)];
+                    mdl[j] = MD(k, i + j);
+                    enp[j] = EP(k, i + j);
+                }
+
+                flag_lossless(limit, prepoint, postpoint, prepoint_x, postpoint_x, res[k], mdl, enp, floor[k], flag[k],
+                              i, jn);
+
+                for (j = 0; j < jn; j++) {
+                    quant[k][j] = raw[k][j] = mdl[j] * mdl[j];
+                    if (mdl[j] < 0.f) raw[k][j] *= -1.f;
+                    floor[k][j] *= floor[k][j];
+                }
+
+                acc[track] = noise_normalize(p, limit, raw[k], quant[k], floor[k], res[k], nullptr, acc[track],
+                                             NP(k, pi), i, jn, &IW(k, i), L);
+            } else {
+                for (j = 0; j < jn; j++) {
+                    floor[k][j] = 1e-10f;
+                    raw[k][j] = 0.f;
+                    quant[k][j] = 0.f;
+                    res[k][j] = 0.f;
+                    flag[k][j] = 0;
+                    IW(k, i + j) = 0;
+                }
+                acc[track] = 0.f;
+            }
+            track++;
+        }
+
+        // coupling
+        for (step = 0; step < vi->coupling_steps; step++) {
+            int Mi = vi->coupling_mag[step];
+            int Ai = vi->coupling_ang[step];
+            float *reM = raw[Mi], *reA = raw[Ai];
+            float *qeM = quant[Mi], *qeA = quant[Ai];
+            float *floorM = floor[Mi], *floorA = floor[Ai];
+            float *resM = res[Mi], *resA = res[Ai];
+            int *fM = flag[Mi], *fA = flag[Ai];
+            int pointflag = 0;
+
+            if (nz[Mi] || nz[Ai]) {
+                nz[Mi] = nz[Ai] = 1;
+
+                // M6
+                if (p->tonefix_end > i) {
+                    int rp = 0, pp = 0, ap;
+                    float residue_def = 0;
+
+                    for (j = 0; j < jn; j++) {
+                        if (existe(resM[j], 0.5) || existe(resA[j], 0.5)) {
+                            if (refer_phase(reM[j], reA[j])) rp++;
+                            else pp++;
+                            residue_def = (float)((double)residue_def +
+                                                  fabs((double)fabsf(resM[j]) - (double)fabsf(resA[j])));
+                        }
+                    }
+                    ap = rp + pp;
+
+                    if (ap != 0) {
+                        float temp_def = residue_def = residue_def / ap;
+                        if (side_resdef[step] > 0)
+                            residue_def = (float)((double)temp_def * 0.5 + (double)side_resdef[step] * 0.5);
+                        side_resdef[step] = temp_def;
+                        if (residue_def > 1.f) {
+                            for (j = 0; j < jn; j++)
+                                if (fM[j] == -1 || fA[j] == -1) fM[j] = 1;
+                        }
+                        if ((float)rp / ap >= prae) {
+                            for (j = 0; j < jn; j++)
+                                if ((fM[j] == -1 || fA[j] == -1) && refer_phase(reM[j], reA[j])) fM[j] = 1;
+                        }
+                    } else
+                        side_resdef[step] = -1.f;
+                }
+
+                for (j = 0; j < jn; j++) {
+                    if (j < sliding_lowpass - i) {
+                        if (fM[j] == 1 || fA[j] == 1) {
+                            // lossless coupling
+                            reM[j] = fabsf(reM[j]) + fabsf(reA[j]);
+                            qeM[j] = qeM[j] + qeA[j];
+                            fM[j] = fA[j] = 1;
+
+                            lossless_couplingf(&resM[j], &resA[j]);
+                            int m = IW(Mi, i + j), a = IW(Ai, i + j);
+                            lossless_coupling(&m, &a);
+                            IW(Mi, i + j) = m;
+                            IW(Ai, i + j) = a;
+                        } else {
+                            // lossy (point) coupling
+                            float hpL, hpH;
+                            if (vi->coupling_steps == 1 || step == 3) {
+                                hpL = .18f;
+                                hpH = .12f;
+                            } else {
+                                hpL = .18f;
+                                hpH = .04f;
+                            }
+                            if (j < limit - i) reM[j] = min_indemnity_dipole_hypot(reM[j], reA[j], hpL);
+                            else reM[j] = min_indemnity_dipole_hypot(reM[j], reA[j], hpH);
+
+                            qeM[j] = fabsf(reM[j]);
+                            reA[j] = qeA[j] = 0.f;
+                            fA[j] = 1;
+                            IW(Ai, i + j) = 0;
+                            resA[j] = 0;
+
+                            float npM = NP(Mi, pi), npA = NP(Ai, pi);
+                            if (((double)npM < -0.5) || ((double)npA < -0.5)) NP(Mi, pi) = -1;
+                            else NP(Mi, pi) = VMIN(npM, npA);
+
+                            pointflag |= 1;
+                        }
+                    }
+                    floorM[j] = floorA[j] = floorM[j] + floorA[j];
+                }
+                if (pointflag)
+                    acc[track] = noise_normalize(p, limit, raw[Mi], quant[Mi], floor[Mi], res[Mi], flag[Mi], acc[track],
+                                                 NP(Mi, pi), i, jn, &IW(Mi, i), L);
+                track++;
+            }
+        }
+    }
+
+    if (lowpassr < n) {
+        for (int k = 0; k < ch; k++)
+            for (int j = lowpassr; j < n; j++) IW(k, j) = 0;
+    }
+
+    for (i = 0; i < vi->coupling_steps; i++) {
+        if (nonzero[vi->coupling_mag[i]] || nonzero[vi->coupling_ang[i]]) {
+            nonzero[vi->coupling_mag[i]] = 1;
+            nonzero[vi->coupling_ang[i]] = 1;
+        }
+    }
+    for (i = 0; i < ch; i++) b.nonzero[col0 + i] = nonzero[i];
+#undef MD
+#undef EP
+#undef NP
+#undef IW
+}
+
+}  // namespace
+
+extern "C" int vbm_launch_couple_quantize(const vbm_batch *b, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_couple_quantize, dim3((unsigned)((b->nsb + 63) / 64)), dim3(64), 0, st, *b);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}

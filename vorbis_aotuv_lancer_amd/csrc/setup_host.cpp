@@ -409,6 +409,7 @@ struct vbm_setup_host {
     // device
     unsigned char *d_arena = nullptr;
     vbm_setup *d_setup = nullptr;
+    vbm_setup dev_view;             // host-resident struct whose pointers are DEVICE addresses
 };
 
 static void rebase_setup(vbm_setup &s, const unsigned char *base)
@@ -657,6 +658,7 @@ int vbm_setup_host_upload(vbm_setup_host *H)
         return vbm_set_hip_error(e, "hipMemcpy(setup arena)");
     vbm_setup dev = H->s;
     rebase_setup(dev, H->d_arena);
+    H->dev_view = dev;
     if ((e = hipMalloc((void **)&H->d_setup, sizeof(vbm_setup))) != hipSuccess)
         return vbm_set_hip_error(e, "hipMalloc(setup)");
     if ((e = hipMemcpy(H->d_setup, &dev, sizeof(dev), hipMemcpyHostToDevice)) != hipSuccess)
@@ -665,6 +667,7 @@ int vbm_setup_host_upload(vbm_setup_host *H)
 }
 
 const vbm_setup *vbm_setup_device(const vbm_setup_host *H) { return H->d_setup; }
+const vbm_setup *vbm_setup_device_ptrs(const vbm_setup_host *H) { return &H->dev_view; }
 
 void vbm_setup_host_free(vbm_setup_host *H)
 {

@@ -1,0 +1,99 @@
+"""Batched encoder — host mirror of the reference's per-block encode calls
+(vorbis_analysis / vorbis_bitrate_addblock / vorbis_bitrate_flushpacket, reference
+lib/analysis.c:29, lib/bitrate.c:73, :229) over the C ABI of include/vorbis_mi355x.h."""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from ._lib import lib, check
+
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+
+
+def mode_pack_path(channels, rate, quality):
+    return os.path.join(_DATA, f"mode_{channels}ch_{rate}_q{quality:g}.vpk")
+
+
+class Setup:
+    """codec_setup_info + looks for one (channels, rate, quality) class (vorbis_encode_init_vbr +
+    vorbis_analysis_init in the reference), loaded from the shipped mode pack."""
+
+    def __init__(self, channels, rate, quality):
+        self.channels, self.rate, self.quality = channels, rate, quality
+        self._h = C.c_void_p()
+        path = mode_pack_path(channels, rate, quality)
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"no mode pack for {channels} ch / {rate} Hz / q{quality:g}: {path} "
+                                    "(generate one with tools/make_modepack.py)")
+        check(lib.vbm_setup_create(C.byref(self._h), os.path.join(_DATA, "common.vpk").encode(), path.encode()),
+              "vbm_setup_create")
+        info = self.table("info")
+        self.blocksizes = (int(info[2]), int(info[3]))
+
+    def table(self, name):
+        data, count, kind = C.c_void_p(), C.c_long(), C.c_char()
+        check(lib.vbm_setup_table(self._h, name.encode(), C.byref(data), C.byref(count), C.byref(kind)),
+              f"vbm_setup_table({name})")
+        dt = {b"f": np.float32, b"i": np.int32, b"u": np.uint32, b"b": np.int8, b"d": np.float64}[kind.value]
+        buf = (C.c_char * (count.value * np.dtype(dt).itemsize)).from_address(data.value)
+        return np.frombuffer(buf, dtype=dt).copy()
+
+    def close(self):
+        if self._h:
+            lib.vbm_setup_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+class Encoder:
+    """Device-resident state of `nstreams` encoder streams + batch workspace."""
+
+    def __init__(self, setup, nstreams, max_batch=None):
+        self.setup = setup
+        self.nstreams = nstreams
+        self.max_batch = max_batch or nstreams
+        self._h = C.c_void_p()
+        check(lib.vbm_encoder_create(C.byref(self._h), setup._h, nstreams, self.max_batch), "vbm_encoder_create")
+        self.max_packet_bytes = lib.vbm_encoder_max_packet_bytes(self._h)
+
+    def reset(self):
+        check(lib.vbm_encoder_reset(self._h), "vbm_encoder_reset")
+
+    def analysis_batch(self, block_mode, stream_ids, wflags, pcm):
+        """pcm: CUDA float32 tensor [nsb, channels, blocksize]; returns (packets uint8 [nsb, max_bytes],
+        nbytes int32 [nsb]) on the device."""
+        ids = np.ascontiguousarray(stream_ids, dtype=np.int32)
+        fl = np.ascontiguousarray(wflags, dtype=np.uint8)
+        nsb = len(ids)
+        N = self.setup.blocksizes[block_mode >> 1]
+        if not (pcm.is_cuda and pcm.dtype == torch.float32 and pcm.is_contiguous()
+                and tuple(pcm.shape) == (nsb, self.setup.channels, N)):
+            raise ValueError(f"pcm must be a contiguous CUDA float32 tensor of shape ({nsb}, {self.setup.channels}, {N})")
+        packets = torch.empty((nsb, self.max_packet_bytes), dtype=torch.uint8, device=pcm.device)
+        nbytes = torch.empty((nsb,), dtype=torch.int32, device=pcm.device)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(lib.vbm_analysis_batch(self._h, block_mode, nsb, ids.ctypes.data, fl.ctypes.data, pcm.data_ptr(),
+                                     packets.data_ptr(), nbytes.data_ptr(), st), "vbm_analysis_batch")
+        self._last = (nsb, pcm.device)
+        return packets, nbytes
+
+    def fetch(self, name):
+        """Intermediate of the last batch as a CUDA tensor, block-major."""
+        nsb, dev = self._last
+        rows, kind = C.c_long(), C.c_char()
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(lib.vbm_encoder_fetch(self._h, name.encode(), None, C.byref(rows), C.byref(kind), st), "vbm_encoder_fetch")
+        dt = torch.float32 if kind.value == b"f" else torch.int32
+        per_sb = name in ("global_ampmax", "packet_bytes")
+        count = nsb if per_sb else nsb * self.setup.channels
+        shape = (count,) if rows.value == 1 else (count, rows.value)
+        out = torch.empty(shape, dtype=dt, device=dev)
+        check(lib.vbm_encoder_fetch(self._h, name.encode(), out.data_ptr(), C.byref(rows), C.byref(kind), st),
+              "vbm_encoder_fetch")
+        return out
+
+    def close(self):
+        if self._h:
+            lib.vbm_encoder_destroy(self._h)
+            self._h = C.c_void_p()
