@@ -1,22 +1,22 @@
 #!/usr/bin/env python3
-"""Headline benchmark of the MI355X batched Vorbis encode path.
+"""Headline benchmark of the MI355X batched Vorbis (aoTuV) encode path.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1]): 4096 concurrent 44.1 kHz stereo q5 streams per GPU,
-long blocks (2048 samples), synthetic PCM already resident in HBM.  One "step" = one pass of
-the implemented hot-path stages over one batch of BLOCKS_PER_STREAM consecutive long blocks
-of every stream (each long block advances a stream by 1024 samples).  Streams shard across
-ranks with no data-path collective, so scaling is weak: every rank encodes
-its own 4096 streams; `value` = audio seconds encoded by all ranks / max-over-ranks wall time.
+Workload = BASELINE.json configs[1] geometry: 4096 concurrent 44.1 kHz stereo q5 streams per
+GPU, long blocks (2048 samples), synthetic PCM already resident in HBM — but with the WHOLE
+per-block path on the device (window, MDCT, FFT, psy, floor fit/encode, couple/quantise, residue
+VQ, packet assembly), i.e. nothing is left to the host, so the number is not inflated by skipped
+work.  One "step" = vbm_analysis_batch over one long block of every stream (each step advances
+every stream by 1024 samples = 23.2 ms of audio; consecutive steps feed consecutive overlapping
+blocks so the carried aoTuV state evolves as in a real encode).  Packets stay on the device.
 
-The JSON line carries which stages are inside the timed region (`config.stages`): until
-the whole pipe of SURVEY.md §8a is on the device, `value` covers only those stages and
-`config.pipeline_complete` is false.
+Streams shard across ranks with no data-path collective: weak scaling, every
+rank encodes its own 4096 streams; value = audio seconds encoded by all ranks / max-over-ranks
+wall time = number of streams that could be encoded at 1x realtime.
 """
 import argparse
-import ctypes as C
 import json
 import os
 import sys
@@ -31,58 +31,75 @@ sys.path.insert(0, ROOT)
 STREAMS_PER_GPU = 4096
 CHANNELS = 2
 RATE = 44100
+QUALITY = 0.5
 N_LONG = 2048
-BLOCKS_PER_STREAM = 16          # long blocks per stream per step (16 hops = 0.3715 s of audio)
+HOP = N_LONG // 2
+DISTINCT_STEPS = 16             # PCM for this many consecutive blocks per stream is kept in HBM
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-MDCT_BYTES_PER_BLOCK = 6 * N_LONG  # read N*4 + write (N/2)*4 per (block, channel)
+
+# algorithmic HBM bytes per long channel-block and stage (SURVEY.md §8d; DESIGN.md §4)
+n = N_LONG // 2
+STAGE_BYTES = {
+    "window_mdct": 4 * N_LONG + 4 * n,              # 12 288: read block, write spectrum
+    "window_fft_log": 4 * N_LONG + 4 * n + 4,       # read block, write logfft + ampmax
+    "transpose": 2 * (4 * n + 4 * n),               # mdct and logfft, read + write
+    "prologue": 16,
+    "noisemask": 4 * n * 2 + 4 * n * 3 + 4 * 32,    # mdct, lastmdct in; logmdct, noise, epeak, npeak out
+    "tonemask": 4 * n + 4 * n,                      # logfft in, tone out
+    "offset_and_mix": 4 * n * 4 + 4 * n * 3,        # noise, tone, logmdct, mdct in; logmask, mdct, lastmdct out
+    "floor_fit": 4 * 905 * 2 + 4 * 29,              # first 905 bins of logmdct + logmask in, posts out
+    "floor_encode": 4 * 29 * 2 + 4 * n,             # posts in, deviations + ilogmask out
+    "couple_quantize": 4 * 928 * 3 + 4 * 928,       # mdct, epeak, ilogmask in, residue out (to lowpass)
+    "pack": 4 * 912 + 240,                          # residue in, ~240 B packet out per channel
+    "packet_out": 2 * 240,
+}
 
 
-def synth_pcm(nblocks, device, seed):
-    """Deterministic synthetic block-major PCM in [-1, 1): two sines + noise per block row."""
-    g = torch.Generator(device=device).manual_seed(seed)
-    t = torch.arange(N_LONG, device=device, dtype=torch.float32) / RATE
-    f1 = 110.0 + 1650.0 * torch.rand((nblocks, 1), generator=g, device=device)
-    f2 = 2000.0 + 4000.0 * torch.rand((nblocks, 1), generator=g, device=device)
-    x = 0.3 * torch.sin(2 * np.pi * f1 * t) + 0.2 * torch.sin(2 * np.pi * f2 * t)
-    x += 0.05 * (2 * torch.rand((nblocks, N_LONG), generator=g, device=device) - 1)
-    return x.contiguous()
+def synth_blocks(dev, seed):
+    """[DISTINCT_STEPS][streams][ch][N] block-major PCM cut from one continuous signal per stream."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    S, C = STREAMS_PER_GPU, CHANNELS
+    total = (DISTINCT_STEPS + 1) * HOP
+    t = torch.arange(total, device=dev, dtype=torch.float32) / RATE
+    f1 = 110.0 + 1650.0 * torch.rand((S, 1, 1), generator=g, device=dev)
+    f2 = 2000.0 + 4000.0 * torch.rand((S, 1, 1), generator=g, device=dev)
+    chan = torch.arange(1, C + 1, device=dev, dtype=torch.float32).view(1, C, 1)
+    x = 0.3 * torch.sin(2 * np.pi * f1 * chan * t) + 0.2 * torch.sin(2 * np.pi * f2 * t + chan)
+    x += 0.05 * (2 * torch.rand((S, C, total), generator=g, device=dev) - 1)
+    blocks = [x[:, :, k * HOP:k * HOP + N_LONG].contiguous() for k in range(DISTINCT_STEPS)]
+    return blocks
 
 
-def cpu_baseline(sample_blocks=4096):
-    """Oracle (CPU restatement, 1 thread) on a bounded sample of the same workload."""
+def cpu_baseline(seconds_of_audio=900):
+    """The oracle's full encoder (CPU restatement, bit-identical to the reference's scalar build,
+    1 thread) on a bounded sample: one stereo q5 stream of the survey probe signal."""
     import subprocess
     so = os.path.join(ROOT, "oracle", "build", "liboracle.so")
     if not os.path.exists(so):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
     from tests import orc
-    from vorbis_aotuv_lancer_amd.tables import window_table
     o = orc.Oracle(so)
-    rng = np.random.default_rng(0)
-    x = (rng.random((sample_blocks, N_LONG), dtype=np.float32) - 0.5)
-    wl = window_table(N_LONG)
-    t0 = time.perf_counter()
-    o.mdct_forward(o.apply_window(x, wl, wl))
-    dt = time.perf_counter() - t0
-    audio_s = sample_blocks / CHANNELS * (N_LONG // 2) / RATE
-    return {"value": audio_s / dt, "unit": "realtime-stream-equivalents (same stages)", "cores": 1,
-            "kind": "port",
-            "sample": f"{sample_blocks} long channel-blocks, window+mdct_forward only, oracle/ scalar C, 1 thread"}
+    st = orc.Setup(o, CHANNELS, RATE, QUALITY)
+    npk, secs = st.encode_probe(seconds_of_audio)
+    return {"value": seconds_of_audio / secs, "unit": "x realtime per core (= streams at 1x per core)",
+            "cores": 1, "kind": "port",
+            "sample": f"{seconds_of_audio} s of 44.1 kHz stereo q5 (survey probe signal, {npk} packets, "
+                      f"block switching + envelope search included), oracle/ scalar C, 1 thread, {secs:.1f} s CPU"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the encode path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -96,72 +113,86 @@ def main():
 
     import vorbis_aotuv_lancer_amd as v
 
-    nblocks = STREAMS_PER_GPU * CHANNELS * BLOCKS_PER_STREAM
-    pcm = synth_pcm(nblocks, dev, seed=1234 + rank)   # resident in HBM before timing starts
-    spec = torch.empty((nblocks, N_LONG // 2), device=dev, dtype=torch.float32)
-    lookup = v.MdctLookup(N_LONG, short_n=256)
-    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    setup = v.Setup(CHANNELS, RATE, QUALITY)
+    enc = v.Encoder(setup, STREAMS_PER_GPU)
+    blocks = synth_blocks(dev, seed=1234 + rank)      # resident in HBM before timing starts
+    ids = np.arange(STREAMS_PER_GPU, dtype=np.int32)
+    wflags = np.full(STREAMS_PER_GPU, 3, dtype=np.uint8)   # lW = nW = long
+    LONG = 3
 
-    def step():
-        v.check(v.lib.vbm_window_mdct_batch(lookup._h, pcm.data_ptr(), spec.data_ptr(), None, nblocks, stream),
-                "vbm_window_mdct_batch")
+    def step(k):
+        return enc.analysis_batch(LONG, ids, wflags, blocks[k % DISTINCT_STEPS])
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for k in range(args.warmup):
+        step(k)
     barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    enc.profile_begin(args.steps)      # HIP events between the stage kernels, on the launch stream
     t0 = time.perf_counter()
-    for a, b in ev:
-        a.record()          # torch's current stream == the stream the kernel is launched on
-        step()
-        b.record()
+    for k in range(args.steps):
+        pk, nb = step(args.warmup + k)
     barrier()
     dt = time.perf_counter() - t0
+    stage_ms, calls = enc.profile_end()
     if dist is not None:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
-    audio_s_per_step = STREAMS_PER_GPU * BLOCKS_PER_STREAM * (N_LONG // 2) / RATE * world
+    audio_s_per_step = STREAMS_PER_GPU * HOP / RATE * world
     value = audio_s_per_step * args.steps / dt
-    achieved = MDCT_BYTES_PER_BLOCK * nblocks / (kernel_ms * 1e-3) / 1e9
+    ncb = STREAMS_PER_GPU * CHANNELS
+    per_launch_ms = {k: ms / max(calls, 1) for k, ms in stage_ms.items()}
+    dominant = max(per_launch_ms, key=per_launch_ms.get)
 
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "mdct_pmc_traffic.json")
+    def roof(stage):
+        ms = per_launch_ms[stage]
+        ach = STAGE_BYTES[stage] * ncb / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        return {"kernel": stage, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBPS, "traffic": None,
+                "algorithmic_bytes_per_launch": STAGE_BYTES[stage] * ncb, "kernel_ms": ms}
+
+    traffic = {}
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
-        if tj.get("nblocks") == nblocks:
-            traffic = tj.get("hbm_bytes_per_launch")
+        if tj.get("channel_blocks_per_launch") == ncb:
+            traffic = tj.get("hbm_bytes_per_launch", {})
 
     if rank == 0:
+        r_dom = roof(dominant)
+        r_dom["traffic"] = traffic.get(dominant)
+        r_mdct = roof("window_mdct")
+        r_mdct["traffic"] = traffic.get("window_mdct")
+        mean_bytes = float(nb.float().mean().item())
         line = {
             "metric": "realtime-stream-equivalents/node (44.1kHz stereo q5) + MDCT HBM GB/s",
             "value": value,
-            "unit": "x realtime (concurrent 44.1 kHz stereo streams encodable at 1x)",
+            "unit": "x realtime (concurrent 44.1 kHz stereo q5 streams encodable at 1x)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": "configs[1]: 4096 streams/GPU x 44.1 kHz stereo q5, long blocks (2048), "
-                            f"{BLOCKS_PER_STREAM} blocks/stream/step, PCM resident in HBM",
+                "workload": "configs[1] geometry: 4096 streams/GPU x 44.1 kHz stereo q5, long blocks (2048), "
+                            "one block per stream per step, PCM resident in HBM; full per-block path on the "
+                            "device incl. residue VQ and packet assembly (nothing left to the host)",
                 "streams_per_gpu": STREAMS_PER_GPU, "channels": CHANNELS, "blocksize": N_LONG,
-                "blocks_per_step": nblocks * world,
-                "stages": ["window", "mdct_forward"],
-                "pipeline_complete": False,
+                "channel_blocks_per_step": ncb * world,
+                "stages": list(stage_ms.keys()),
+                "pipeline_complete": True,
+                "block_switching": "not in the timed region (long blocks only; envelope search / carve-out is "
+                                   "SURVEY.md §8f N1)",
+                "mean_packet_bytes": mean_bytes,
                 "parallelism": f"stream-shard x{world} (no collective)",
             },
-            "roofline": {"kernel": "k_window_mdct<2048>", "bound": "hbm", "achieved": achieved,
-                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic,
-                         "algorithmic_bytes_per_launch": MDCT_BYTES_PER_BLOCK * nblocks,
-                         "kernel_ms": kernel_ms},
+            "roofline": r_dom,
+            "mdct_roofline": r_mdct,
+            "stage_ms_per_launch": per_launch_ms,
         }
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()

@@ -142,6 +142,15 @@ int vbm_analysis_batch(vbm_encoder *enc, int block_mode, int nsb, const int *str
  * "poste" "packet_bytes".  d_out may be NULL to query rows/kind ('f' float32, 'i' int32). */
 int vbm_encoder_fetch(vbm_encoder *enc, const char *name, void *d_out, long *rows, char *kind, void *stream);
 
+/* Per-stage timing of vbm_analysis_batch: HIP events are recorded on the launch stream between
+ * the pipeline's kernels for the next `max_calls` calls; profile_end waits for the last one and
+ * returns the summed milliseconds per stage (vbm_encoder_stage_count() entries, names from
+ * vbm_encoder_stage_name) and the number of calls covered. */
+int vbm_encoder_profile_begin(vbm_encoder *enc, int max_calls);
+int vbm_encoder_profile_end(vbm_encoder *enc, float *stage_ms, int *ncalls);
+int vbm_encoder_stage_count(void);
+const char *vbm_encoder_stage_name(int k);
+
 /* Host-only table builders (no device needed): the lookup tables the plans upload, for
  * integrators and for CPU-side parity checks.
  *   vbm_host_mdct_trig     n + n/4 floats  (mdct_init, lib/mdct.c:67-76)

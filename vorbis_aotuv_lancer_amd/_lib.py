@@ -47,6 +47,10 @@ SIGNATURES = {
                                      C.c_void_p, C.c_void_p]),
     "vbm_encoder_fetch": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_char),
                                     C.c_void_p]),
+    "vbm_encoder_profile_begin": (C.c_int, [C.c_void_p, C.c_int]),
+    "vbm_encoder_profile_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "vbm_encoder_stage_count": (C.c_int, []),
+    "vbm_encoder_stage_name": (C.c_char_p, [C.c_int]),
     "vbm_host_mdct_trig": (C.c_int, [C.c_int, C.c_void_p]),
     "vbm_host_fft_twiddles": (C.c_int, [C.c_int, C.c_void_p]),
     "vbm_window_mdct_time": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int,

@@ -34,7 +34,16 @@ struct vbm_encoder {
     uint8_t *d_wflags;
     // last batch (for vbm_encoder_fetch)
     int last_nsb, last_mode;
+    // optional per-stage timing (HIP events on the launch stream)
+    bool profiling = false;
+    std::vector<hipEvent_t> events;   // (NSTAGES+1) per recorded call
+    size_t events_used = 0;
 };
+
+static const char *const kStageNames[] = {"window_mdct", "window_fft_log", "transpose", "prologue", "noisemask",
+                                          "tonemask", "offset_and_mix", "floor_fit", "floor_encode",
+                                          "couple_quantize", "pack", "packet_out"};
+static const int kNumStages = (int)(sizeof(kStageNames) / sizeof(kStageNames[0]));
 
 static int round64(int x) { return (x + 63) & ~63; }
 
@@ -55,6 +64,7 @@ extern "C" void vbm_encoder_destroy(vbm_encoder *e)
 {
     if (!e) return;
     for (void *p : e->allocs) (void)hipFree(p);
+    for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
     delete e;
 }
 
@@ -213,35 +223,93 @@ extern "C" int vbm_analysis_batch(vbm_encoder *e, int block_mode, int nsb, const
 
     int W = b.W;
     int rc = 0;
+    const bool prof = e->profiling && e->events_used + kNumStages + 1 <= e->events.size();
+    size_t ev = e->events_used;
+#define MARK() do { if (prof) (void)hipEventRecord(e->events[ev++], st); } while (0)
 #define RUN(x) do { rc = (x); if (rc) { g_vbm_err = std::string("launch failed: ") + #x; return VBM_EHIP; } } while (0)
     RUN(vbm_launch_spread_flags(&b, st));
+    MARK();
     // loop A: window + MDCT, window + FFT + log spectrum (wave per block)
     RUN(vbm_launch_window_mdct(b.pcm, b.mdct_bm, W ? b.wflags_cb : nullptr, vbm_setup_device_ptrs(e->H)->mdct_trig[W],
                                vbm_setup_device_ptrs(e->H)->window[W], vbm_setup_device_ptrs(e->H)->window[0], b.N,
                                s->blocksizes[0], 1, b.ncb, 0, st));
+    MARK();
     RUN(vbm_launch_window_fft_log(b.pcm, b.logfft_bm, b.local_ampmax, W ? b.wflags_cb : nullptr,
                                   vbm_setup_device_ptrs(e->H)->fft_wa[W], vbm_setup_device_ptrs(e->H)->window[W],
                                   vbm_setup_device_ptrs(e->H)->window[0], b.N, s->blocksizes[0], b.ncb, st));
+    MARK();
     RUN(vbm_launch_transpose_in(&b, st));
+    MARK();
     // loop B: psychoacoustics + floor fit (lane per channel-block)
     RUN(vbm_launch_prologue(&b, st));
+    MARK();
     RUN(vbm_launch_noisemask(&b, st));
+    MARK();
     RUN(vbm_launch_tonemask(&b, st));
+    MARK();
     RUN(vbm_launch_mix(&b, st));
+    MARK();
     RUN(vbm_launch_floor_fit(&b, st));
+    MARK();
     // loop C: floor encode, couple/quantise, residue + packet assembly
     RUN(vbm_launch_floor_encode(&b, st));
+    MARK();
     RUN(vbm_launch_couple_quantize(&b, st));
+    MARK();
     RUN(vbm_launch_pack(&b, st));
+    MARK();
     if (d_packets)
         RUN(vbm_launch_untranspose_u8(b.packetT, d_packets, e->max_packet_bytes, b.Ls, nsb, st));
     if (d_packet_bytes) {
         if ((err = hipMemcpyAsync(d_packet_bytes, b.packet_bytes, nsb * sizeof(int), hipMemcpyDeviceToDevice, st)) != hipSuccess)
             return vbm_set_hip_error(err, "hipMemcpyAsync(packet_bytes)");
     }
+    MARK();
+    if (prof) e->events_used = ev;
 #undef RUN
+#undef MARK
     return VBM_OK;
 }
+
+extern "C" int vbm_encoder_profile_begin(vbm_encoder *e, int max_calls)
+{
+    if (!e || max_calls <= 0) return VBM_EINVAL;
+    size_t need = (size_t)max_calls * (kNumStages + 1);
+    while (e->events.size() < need) {
+        hipEvent_t ev;
+        hipError_t err = hipEventCreate(&ev);
+        if (err != hipSuccess) return vbm_set_hip_error(err, "hipEventCreate");
+        e->events.push_back(ev);
+    }
+    e->events_used = 0;
+    e->profiling = true;
+    return VBM_OK;
+}
+
+extern "C" int vbm_encoder_profile_end(vbm_encoder *e, float *stage_ms, int *ncalls)
+{
+    if (!e || !stage_ms) return VBM_EINVAL;
+    e->profiling = false;
+    int calls = (int)(e->events_used / (kNumStages + 1));
+    for (int k = 0; k < kNumStages; k++) stage_ms[k] = 0.f;
+    if (calls > 0) {
+        hipError_t err = hipEventSynchronize(e->events[e->events_used - 1]);
+        if (err != hipSuccess) return vbm_set_hip_error(err, "hipEventSynchronize");
+        for (int c = 0; c < calls; c++)
+            for (int k = 0; k < kNumStages; k++) {
+                float ms = 0.f;
+                (void)hipEventElapsedTime(&ms, e->events[(size_t)c * (kNumStages + 1) + k],
+                                          e->events[(size_t)c * (kNumStages + 1) + k + 1]);
+                stage_ms[k] += ms;
+            }
+    }
+    if (ncalls) *ncalls = calls;
+    e->events_used = 0;
+    return VBM_OK;
+}
+
+extern "C" int vbm_encoder_stage_count(void) { return kNumStages; }
+extern "C" const char *vbm_encoder_stage_name(int k) { return (k >= 0 && k < kNumStages) ? kStageNames[k] : ""; }
 
 // Stage intermediates of the LAST batch, converted to block-major rows, for parity tests.
 extern "C" int vbm_encoder_fetch(vbm_encoder *e, const char *name, void *d_out, long *rows_out, char *kind,

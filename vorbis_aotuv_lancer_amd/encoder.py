@@ -93,6 +93,17 @@ class Encoder:
               "vbm_encoder_fetch")
         return out
 
+    def profile_begin(self, max_calls):
+        check(lib.vbm_encoder_profile_begin(self._h, max_calls), "vbm_encoder_profile_begin")
+
+    def profile_end(self):
+        """-> ({stage name: total ms}, calls covered)"""
+        n = lib.vbm_encoder_stage_count()
+        ms = (C.c_float * n)()
+        calls = C.c_int()
+        check(lib.vbm_encoder_profile_end(self._h, ms, C.byref(calls)), "vbm_encoder_profile_end")
+        return {lib.vbm_encoder_stage_name(k).decode(): float(ms[k]) for k in range(n)}, calls.value
+
     def close(self):
         if self._h:
             lib.vbm_encoder_destroy(self._h)
