@@ -28,7 +28,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-STREAMS_PER_GPU = 4096
+STREAMS_PER_GPU = int(os.environ.get("VBM_BENCH_STREAMS", "4096"))
 CHANNELS = 2
 RATE = 44100
 QUALITY = 0.5

@@ -14,9 +14,10 @@
 
 struct vbm_stream_state {           // per-encoder, S streams (reference lib/codec_internal.h:85-92,
     int S, ch;                      //  vorbis_block_internal.ampmax, vorbis_look_psy_global.ampmax)
-    int Lc;                         // S*ch rounded up to 64: leading dimension of the per-channel arrays
-    float *mblock;                  // [2048][Lc]  lW logmdct buffer (lastmdct)
-    float *tblock;                  // [256][Lc]   temporal masking buffer (tempmdct)
+    int Lc;                         // S*ch rounded up to 64
+    size_t slab_words;              // words per 64-column tile of the carried buffers: (2048+256)*64
+    float *mblock;                  // tile layout [col>>6][2048 rows][64]: lW logmdct buffer (lastmdct)
+    float *tblock;                  // = mblock + 2048*64 within each tile: temporal masking buffer (tempmdct)
     float *lowcomp;                 // [Lc]        lownoise_compand_level
     float *g_ampmax;                // [S]         psy_g_look->ampmax
     float *vbi_ampmax;              // [S]         vorbis_block_internal.ampmax of the stream's block
@@ -42,7 +43,15 @@ struct vbm_batch {
     float *logfft_bm;               // [ncb][n]
     float *local_ampmax;            // [ncb]
     uint8_t *wflags_cb;             // [ncb] wflags replicated per channel-block
-    // bin-major stage buffers, leading dimension L
+    // Tiled bin-major stage buffers.  Lanes are grouped in tiles of 64 (one wavefront); each tile
+    // owns one contiguous slab of `slab_words` 4-byte words holding ALL of its arrays, an array
+    // being [rows][64].  Element (row i, lane l) of array X lives at
+    //     X[(l >> 6) * slab_words + i * 64 + (l & 63)]
+    // so a wave walks 256-byte rows that are adjacent in memory (DRAM-page / TLB friendly) and
+    // the row stride is the compile-time constant 64.  The pointers below already include the
+    // array's offset inside the slab.
+    size_t slab_words;
+    size_t sb_slab_words;           // same for the stream-block-lane arrays (partwordT, workvqT)
     float *mdctT, *logfftT, *logmdctT, *noiseT, *toneT, *logmaskT, *epeakT, *workT;
     float *npeakT;                  // [n/partition][L]
     float *sumT;                    // [5][n][L]  N, X, XX, Y, XY of bark_noise_hybridmp

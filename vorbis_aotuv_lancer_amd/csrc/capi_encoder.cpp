@@ -114,8 +114,9 @@ extern "C" int vbm_encoder_create(vbm_encoder **out, vbm_setup_handle *setup, in
     b.st.S = nstreams;
     b.st.ch = e->ch;
     b.st.Lc = round64(nstreams * e->ch);
-    A(b.st.mblock, float, (size_t)2048 * b.st.Lc);
-    A(b.st.tblock, float, (size_t)256 * b.st.Lc);
+    b.st.slab_words = (size_t)(2048 + 256) * 64;
+    A(b.st.mblock, float, (size_t)(b.st.Lc / 64) * b.st.slab_words);
+    b.st.tblock = b.st.mblock + (size_t)2048 * 64;
     A(b.st.lowcomp, float, (size_t)b.st.Lc);
     A(b.st.g_ampmax, float, (size_t)nstreams);
     A(b.st.vbi_ampmax, float, (size_t)nstreams);
@@ -133,29 +134,38 @@ extern "C" int vbm_encoder_create(vbm_encoder **out, vbm_setup_handle *setup, in
     A(b.logfft_bm, float, L * nmax);
     A(b.local_ampmax, float, L);
     A(b.wflags_cb, uint8_t, L);
-    A(b.mdctT, float, L * nmax);
-    A(b.logfftT, float, L * nmax);
-    A(b.logmdctT, float, L * nmax);
-    A(b.noiseT, float, L * nmax);
-    A(b.toneT, float, L * nmax);
-    A(b.logmaskT, float, L * nmax);
-    A(b.epeakT, float, L * nmax);
-    A(b.workT, float, L * nmax);
-    A(b.npeakT, float, L * (nmax / 8 + 1));
-    A(b.sumT, float, L * nmax * 5);
-    A(b.seedT, float, L * e->max_oct);
-    A(b.ampstackT, float, L * e->max_oct);
-    A(b.posstackT, int, L * e->max_oct);
+    // tiled slabs (batch.h): every per-bin array of a 64-lane tile sits in one contiguous slab
+    {
+        size_t rows = 0;
+        auto take = [&](size_t r) { size_t at = rows; rows += r; return at * 64; };
+        const size_t o_mdct = take(nmax), o_logfft = take(nmax), o_logmdct = take(nmax), o_noise = take(nmax),
+                     o_tone = take(nmax), o_logmask = take(nmax), o_epeak = take(nmax), o_work = take(nmax),
+                     o_npeak = take(nmax / 8 + 1), o_sum = take((size_t)5 * nmax), o_seed = take(e->max_oct),
+                     o_amp = take(e->max_oct), o_pos = take(e->max_oct), o_post = take(VBM_VIF_POSIT + 2),
+                     o_fout = take(VBM_VIF_POSIT + 2), o_iwork = take(nmax);
+        b.slab_words = rows * 64;
+        float *slab;
+        A(slab, float, (L / 64) * b.slab_words);
+        b.mdctT = slab + o_mdct; b.logfftT = slab + o_logfft; b.logmdctT = slab + o_logmdct;
+        b.noiseT = slab + o_noise; b.toneT = slab + o_tone; b.logmaskT = slab + o_logmask;
+        b.epeakT = slab + o_epeak; b.workT = slab + o_work; b.npeakT = slab + o_npeak; b.sumT = slab + o_sum;
+        b.seedT = slab + o_seed; b.ampstackT = slab + o_amp; b.posstackT = (int *)(slab + o_pos);
+        b.postT = (int *)(slab + o_post); b.floor_outT = (int *)(slab + o_fout); b.iworkT = (int *)(slab + o_iwork);
+
+        size_t srows = 0;
+        auto stake = [&](size_t r) { size_t at = srows; srows += r; return at * 64; };
+        const size_t o_pw = stake((size_t)e->max_partvals * e->ch), o_vq = stake((size_t)nmax * e->ch);
+        b.sb_slab_words = srows * 64;
+        int *sslab;
+        A(sslab, int, (Ls / 64) * b.sb_slab_words);
+        b.partwordT = sslab + o_pw;
+        b.workvqT = sslab + o_vq;
+    }
     A(b.poste, float, L);
     A(b.global_ampmax, float, Ls);
-    A(b.postT, int, L * (VBM_VIF_POSIT + 2));
     A(b.post_valid, int, L);
-    A(b.floor_outT, int, L * (VBM_VIF_POSIT + 2));
-    A(b.iworkT, int, L * nmax);
     A(b.nonzero, int, L);
-    A(b.partwordT, int, Ls * (size_t)e->max_partvals * e->ch);
-    A(b.workvqT, int, Ls * (size_t)nmax * e->ch);
-    A(b.packetT, uint8_t, Ls * (size_t)e->max_packet_bytes);
+    A(b.packetT, uint8_t, Ls * (size_t)e->max_packet_bytes);   // [sb>>6][max_packet_bytes][64]
     A(b.packet_bytes, int, Ls);
 #undef A
     b.stream_id = e->d_stream_id;
@@ -170,8 +180,7 @@ extern "C" int vbm_encoder_reset(vbm_encoder *e)
 {
     if (!e) return VBM_EINVAL;
     vbm_stream_state &st = e->b.st;
-    (void)hipMemset(st.mblock, 0, (size_t)2048 * st.Lc * sizeof(float));
-    (void)hipMemset(st.tblock, 0, (size_t)256 * st.Lc * sizeof(float));
+    (void)hipMemset(st.mblock, 0, (size_t)(st.Lc / 64) * st.slab_words * sizeof(float));   // mblock + tblock
     (void)hipMemset(st.lowcomp, 0, (size_t)st.Lc * sizeof(float));
     (void)hipMemset(st.lW_block_mode, 0, e->S * sizeof(int));
     (void)hipMemset(st.lW_no, 0, e->S * sizeof(int));
@@ -259,7 +268,8 @@ extern "C" int vbm_analysis_batch(vbm_encoder *e, int block_mode, int nsb, const
     RUN(vbm_launch_pack(&b, st));
     MARK();
     if (d_packets)
-        RUN(vbm_launch_untranspose_u8(b.packetT, d_packets, e->max_packet_bytes, b.Ls, nsb, st));
+        RUN(vbm_launch_untranspose_u8(b.packetT, d_packets, e->max_packet_bytes, (size_t)e->max_packet_bytes * 64,
+                                      nsb, st));
     if (d_packet_bytes) {
         if ((err = hipMemcpyAsync(d_packet_bytes, b.packet_bytes, nsb * sizeof(int), hipMemcpyDeviceToDevice, st)) != hipSuccess)
             return vbm_set_hip_error(err, "hipMemcpyAsync(packet_bytes)");
@@ -347,8 +357,8 @@ extern "C" int vbm_encoder_fetch(vbm_encoder *e, const char *name, void *d_out, 
             return err == hipSuccess ? VBM_OK : vbm_set_hip_error(err, "hipMemcpyAsync(fetch)");
         }
         int rc = (t.kind == 'f')
-                     ? vbm_launch_untranspose_f32((const float *)t.ptr, (float *)d_out, t.rows, b.L, t.lanes, st)
-                     : vbm_launch_untranspose_i32((const int *)t.ptr, (int *)d_out, t.rows, b.L, t.lanes, st);
+                     ? vbm_launch_untranspose_f32((const float *)t.ptr, (float *)d_out, t.rows, b.slab_words, t.lanes, st)
+                     : vbm_launch_untranspose_i32((const int *)t.ptr, (int *)d_out, t.rows, b.slab_words, t.lanes, st);
         return rc ? VBM_EHIP : VBM_OK;
     }
     struct Vec { const char *name; const void *ptr; char kind; int count; };

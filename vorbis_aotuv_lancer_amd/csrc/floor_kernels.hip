@@ -14,7 +14,7 @@
 #include "batch.h"
 #include "kernels.h"
 
-#define T(buf, i) (buf)[(size_t)(i) * L + lane]
+#define T(buf, i) (buf)[tb + (size_t)(i) * 64]   /* tiled bin-major: batch.h */
 
 namespace {
 
@@ -115,7 +115,7 @@ __global__ void k_floor_fit(vbm_batch b)
 {
     const int lane = blockIdx.x * blockDim.x + threadIdx.x;
     if (lane >= b.ncb) return;
-    const int L = b.L;
+    const size_t tb = (size_t)(lane >> 6) * b.slab_words + (lane & 63);
     const vbm_setup *s = b.setup;
     const int c = lane % b.ch;
     const vbm_map *map = &s->map[b.W];
@@ -325,7 +325,7 @@ __global__ void k_floor_encode(vbm_batch b)
 {
     const int lane = blockIdx.x * blockDim.x + threadIdx.x;
     if (lane >= b.ncb) return;
-    const int L = b.L;
+    const size_t tb = (size_t)(lane >> 6) * b.slab_words + (lane & 63);
     const vbm_setup *s = b.setup;
     const int c = lane % b.ch;
     const vbm_map *map = &s->map[b.W];

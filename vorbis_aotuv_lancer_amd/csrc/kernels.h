@@ -13,7 +13,8 @@ int vbm_launch_floor_fit(const vbm_batch *b, hipStream_t st);
 int vbm_launch_floor_encode(const vbm_batch *b, hipStream_t st);
 int vbm_launch_couple_quantize(const vbm_batch *b, hipStream_t st);
 int vbm_launch_pack(const vbm_batch *b, hipStream_t st);
-int vbm_launch_untranspose_f32(const float *srcT, float *dst_bm, int rows, int L, int ncb, hipStream_t st);
-int vbm_launch_untranspose_i32(const int *srcT, int *dst_bm, int rows, int L, int ncb, hipStream_t st);
-int vbm_launch_untranspose_u8(const uint8_t *srcT, uint8_t *dst_bm, int rows, int L, int ncb, hipStream_t st);
+// tiled [col>>6][rows][64] (tile stride `slab` elements) -> block-major dst[col][rows]
+int vbm_launch_untranspose_f32(const float *srcT, float *dst_bm, int rows, size_t slab, int ncols, hipStream_t st);
+int vbm_launch_untranspose_i32(const int *srcT, int *dst_bm, int rows, size_t slab, int ncols, hipStream_t st);
+int vbm_launch_untranspose_u8(const uint8_t *srcT, uint8_t *dst_bm, int rows, size_t slab, int ncols, hipStream_t st);
 }

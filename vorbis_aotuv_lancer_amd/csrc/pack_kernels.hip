@@ -20,7 +20,7 @@ namespace {
 
 struct BitW {
     uint8_t *base;     // &packetT[lane]
-    size_t stride;     // Ls
+    size_t stride;     // 64 (tiled layout)
     int nbytes;
     int maxbytes;
     uint64_t acc;
@@ -171,7 +171,8 @@ __global__ void k_pack(vbm_batch b)
 {
     const int sb = blockIdx.x * blockDim.x + threadIdx.x;
     if (sb >= b.nsb) return;
-    const size_t L = b.L, Ls = b.Ls;
+    const size_t SW = b.slab_words, SWS = b.sb_slab_words;
+    const size_t sbt = (size_t)(sb >> 6) * SWS + (sb & 63);   // this lane in the stream-block slab
     const vbm_setup *s = b.setup;
     const vbm_map *info = &s->map[b.W];
     const int ch = b.ch;
@@ -181,8 +182,8 @@ __global__ void k_pack(vbm_batch b)
     int i, j, k;
 
     BitW w;
-    w.base = b.packetT + sb;
-    w.stride = Ls;
+    w.base = b.packetT + (size_t)(sb >> 6) * b.max_packet_bytes * 64 + (sb & 63);
+    w.stride = 64;
     w.nbytes = 0;
     w.maxbytes = b.max_packet_bytes;
     w.acc = 0;
@@ -205,7 +206,7 @@ __global__ void k_pack(vbm_batch b)
             bw_write(w, 0, 1);
             continue;
         }
-#define OUTV(x) b.floor_outT[(size_t)(x) * L + col]
+#define OUTV(x) b.floor_outT[(size_t)(col >> 6) * SW + (size_t)(x) * 64 + (col & 63)]
         bw_write(w, 1, 1);
         bw_write(w, (uint32_t)OUTV(0), ilog(look->quant_q - 1));
         bw_write(w, (uint32_t)OUTV(1), ilog(look->quant_q - 1));
@@ -268,11 +269,11 @@ __global__ void k_pack(vbm_batch b)
         const int rn = r->end - r->begin;
         const int partvals = rn / samples_per_partition;
         // partword rows: [vector j][partition i], all submaps share the buffer (used one at a time)
-        int *partword = b.partwordT + sb;
-        const size_t pw_stride = Ls;
+        int *partword = b.partwordT + sbt;
+        const size_t pw_stride = 64;
         const int pw_rows = partvals;
 #define PW(jv, iv) partword[((size_t)(jv) * pw_rows + (iv)) * pw_stride]
-#define IWC(cc, x) b.iworkT[(size_t)(x) * L + col0 + (cc)]
+#define IWC(cc, x) b.iworkT[(size_t)((col0 + (cc)) >> 6) * SW + (size_t)(x) * 64 + ((col0 + (cc)) & 63)]
 
         if (r->type == 2) {
             int used = 0;
@@ -299,11 +300,11 @@ __global__ void k_pack(vbm_batch b)
                 }
             }
             // res2_forward: interleave into one vector (lib/res0.c:781-787), then _01forward
-            int *work = b.workvqT + sb;
+            int *work = b.workvqT + sbt;
             for (i = 0; i < nb; i++)
-                for (j = 0, k = i; j < n; j++, k += nb) work[(size_t)k * Ls] = IWC(chlist[i], j);
+                for (j = 0, k = i; j < n; j++, k += nb) work[(size_t)k * 64] = IWC(chlist[i], j);
             int *vec[1] = {work};
-            size_t stride[1] = {Ls};
+            size_t stride[1] = {64};
             forward01(w, s, r, vec, stride, 1, partword, pw_stride, pw_rows);
         } else {
             // res1_class / res1_forward: only the nonzero channels take part (lib/res0.c:715-745)
@@ -313,7 +314,7 @@ __global__ void k_pack(vbm_batch b)
             for (j = 0; j < nb; j++)
                 if (zb[j]) {
                     vec[used] = &IWC(chlist[j], 0);
-                    stride[used] = L;
+                    stride[used] = 64;
                     used++;
                 }
             if (!used) continue;

@@ -21,7 +21,8 @@
 #include "batch.h"
 #include "kernels.h"
 
-#define T(buf, i) (buf)[(size_t)(i) * L + lane]
+#define T(buf, i) (buf)[tb + (size_t)(i) * 64]   /* tiled bin-major: batch.h */
+#define TB(b, lane) ((size_t)((lane) >> 6) * (b).slab_words + ((lane) & 63))
 #define NEGINF -9999.f
 #define VMIN(x, y) ((x) > (y) ? (y) : (x))
 #define VMAX(x, y) ((x) < (y) ? (y) : (x))
@@ -87,14 +88,25 @@ __global__ void k_prologue(vbm_batch b)
 
 // ---------------------------------------------------------------------------------------------
 // bark_noise_hybridmp, lib/psy.c:3480-3638.  f / noise are bin-major columns of this lane.
-__device__ void hybridmp(const vbm_batch &b, const vbm_psy *p, int lane, const float *f, float *noise,
-                         const float offset, const int fixed)
+// The five prefix sums are strictly sequential per lane (source order); to keep the lane from
+// stalling on every element, loads are issued in batches ahead of the dependent arithmetic
+// (the input column for the prefix pass, the ten window-edge sums for the solve passes).
+// The three solve phases of the source (mirrored window / plain window / tail) are bounded by
+// table-only conditions, so their limits are lane-uniform.
+#define HY_PF 8
+#define HY_SB 4
+__device__ void hybridmp(const vbm_batch &b, const vbm_psy *p, int lane, const float *__restrict__ f,
+                         float *__restrict__ noise, const float offset, const int fixed)
 {
-    const int L = b.L, n = p->n;
-    float *N = b.sumT, *X = b.sumT + (size_t)n * L, *XX = b.sumT + (size_t)2 * n * L,
-          *Y = b.sumT + (size_t)3 * n * L, *XY = b.sumT + (size_t)4 * n * L;
+    const size_t tb = TB(b, lane);
+    const int n = p->n;
+    float *__restrict__ N = b.sumT;
+    float *__restrict__ X = b.sumT + (size_t)n * 64;
+    float *__restrict__ XX = b.sumT + (size_t)2 * n * 64;
+    float *__restrict__ Y = b.sumT + (size_t)3 * n * 64;
+    float *__restrict__ XY = b.sumT + (size_t)4 * n * 64;
     float tN, tX, tXX, tY, tXY;
-    int i, lo, hi;
+    int i;
     float R = 0.f, A = 0.f, B = 0.f, D = 1.f;
     float w, x, y;
 
@@ -102,73 +114,92 @@ __device__ void hybridmp(const vbm_batch &b, const vbm_psy *p, int lane, const f
 
     y = T(f, 0) + offset;
     if (y < 1.f) y = 1.f;
-
     w = (float)((double)(y * y) * .5);
-
     tN += w;
     tX += w;
     tY += w * y;
-
     T(N, 0) = tN; T(X, 0) = tX; T(XX, 0) = tXX; T(Y, 0) = tY; T(XY, 0) = tXY;
 
-    for (i = 1, x = 1.f; i < n; i++, x += 1.f) {
-        y = T(f, i) + offset;
-        if (y < 1.f) y = 1.f;
-
-        w = y * y;
-
-        tN += w;
-        tX += w * x;
-        tXX += w * x * x;
-        tY += w * y;
-        tXY += w * x * y;
-
-        T(N, i) = tN; T(X, i) = tX; T(XX, i) = tXX; T(Y, i) = tY; T(XY, i) = tXY;
+    for (i = 1, x = 1.f; i < n; i += HY_PF) {
+        float fv[HY_PF];
+#pragma unroll
+        for (int u = 0; u < HY_PF; u++) fv[u] = (i + u < n) ? T(f, i + u) : 0.f;
+#pragma unroll
+        for (int u = 0; u < HY_PF; u++) {
+            if (i + u < n) {
+                y = fv[u] + offset;
+                if (y < 1.f) y = 1.f;
+                w = y * y;
+                tN += w;
+                tX += w * x;
+                tXX += w * x * x;
+                tY += w * y;
+                tXY += w * x * y;
+                T(N, i + u) = tN; T(X, i + u) = tX; T(XX, i + u) = tXX; T(Y, i + u) = tY; T(XY, i + u) = tXY;
+                x += 1.f;
+            }
+        }
     }
 
-    for (i = 0, x = 0.f; i < n; i++, x += 1.f) {
-        lo = p->bark_lo[i];
-        hi = p->bark_hi[i];
+    // phase limits (lib/psy.c:3543-3544, :3565-3566), identical in every lane
+    int i1 = 0;
+    for (; i1 < n; i1++) {
+        int lo = p->bark_lo[i1], hi = p->bark_hi[i1];
         if (lo >= 0 || -lo >= n) break;
         if (hi >= n) break;
-
-        tN = T(N, hi) + T(N, -lo);
-        tX = T(X, hi) - T(X, -lo);
-        tXX = T(XX, hi) + T(XX, -lo);
-        tY = T(Y, hi) + T(Y, -lo);
-        tXY = T(XY, hi) - T(XY, -lo);
-
-        A = tY * tXX - tX * tXY;
-        B = tN * tXY - tX * tY;
-        D = tN * tXX - tX * tX;
-        R = (A + x * B) / D;
-        if (R < 0.f) R = 0.f;
-
-        T(noise, i) = R - offset;
     }
-
-    for (; i < n; i++, x += 1.f) {
-        lo = p->bark_lo[i];
-        hi = p->bark_hi[i];
+    int i2 = i1;
+    for (; i2 < n; i2++) {
+        int lo = p->bark_lo[i2], hi = p->bark_hi[i2];
         if (lo < 0 || lo >= n) break;
         if (hi >= n) break;
-
-        tN = T(N, hi) - T(N, lo);
-        tX = T(X, hi) - T(X, lo);
-        tXX = T(XX, hi) - T(XX, lo);
-        tY = T(Y, hi) - T(Y, lo);
-        tXY = T(XY, hi) - T(XY, lo);
-
-        A = tY * tXX - tX * tXY;
-        B = tN * tXY - tX * tY;
-        D = tN * tXX - tX * tX;
-        R = (A + x * B) / D;
-        if (R < 0.f) R = 0.f;
-
-        T(noise, i) = R - offset;
     }
 
-    for (; i < n; i++, x += 1.f) {
+#define HY_SOLVE(MIRROR, FIXEDPASS, I0, I1)                                                                    \
+    for (i = (I0); i < (I1); i += HY_SB) {                                                                      \
+        float e[HY_SB][10], prev[HY_SB];                                                                        \
+        _Pragma("unroll") for (int u = 0; u < HY_SB; u++) {                                                     \
+            if (i + u < (I1)) {                                                                                 \
+                int lo, hi;                                                                                     \
+                if (FIXEDPASS) { hi = i + u + fixed / 2; lo = hi - fixed; }                                     \
+                else { lo = p->bark_lo[i + u]; hi = p->bark_hi[i + u]; }                                        \
+                int lo_ = MIRROR ? -lo : lo;                                                                    \
+                e[u][0] = T(N, hi);  e[u][1] = T(N, lo_);                                                       \
+                e[u][2] = T(X, hi);  e[u][3] = T(X, lo_);                                                       \
+                e[u][4] = T(XX, hi); e[u][5] = T(XX, lo_);                                                      \
+                e[u][6] = T(Y, hi);  e[u][7] = T(Y, lo_);                                                       \
+                e[u][8] = T(XY, hi); e[u][9] = T(XY, lo_);                                                      \
+                if (FIXEDPASS) prev[u] = T(noise, i + u);                                                       \
+            }                                                                                                   \
+        }                                                                                                       \
+        _Pragma("unroll") for (int u = 0; u < HY_SB; u++) {                                                     \
+            if (i + u < (I1)) {                                                                                 \
+                x = (float)(i + u);                                                                             \
+                if (MIRROR) {                                                                                   \
+                    tN = e[u][0] + e[u][1]; tX = e[u][2] - e[u][3]; tXX = e[u][4] + e[u][5];                    \
+                    tY = e[u][6] + e[u][7]; tXY = e[u][8] - e[u][9];                                            \
+                } else {                                                                                        \
+                    tN = e[u][0] - e[u][1]; tX = e[u][2] - e[u][3]; tXX = e[u][4] - e[u][5];                    \
+                    tY = e[u][6] - e[u][7]; tXY = e[u][8] - e[u][9];                                            \
+                }                                                                                               \
+                A = tY * tXX - tX * tXY;                                                                        \
+                B = tN * tXY - tX * tY;                                                                         \
+                D = tN * tXX - tX * tX;                                                                         \
+                R = (A + x * B) / D;                                                                            \
+                if (FIXEDPASS) {                                                                                \
+                    if (R - offset < prev[u]) T(noise, i + u) = R - offset;                                     \
+                } else {                                                                                        \
+                    if (R < 0.f) R = 0.f;                                                                       \
+                    T(noise, i + u) = R - offset;                                                               \
+                }                                                                                               \
+            }                                                                                                   \
+        }                                                                                                       \
+    }
+
+    HY_SOLVE(true, false, 0, i1)
+    HY_SOLVE(false, false, i1, i2)
+    for (i = i2; i < n; i++) {   // x is exactly (float)i in the source as well (x += 1.f from 0, i < 2^24)
+        x = (float)i;
         R = (A + x * B) / D;
         if (R < 0.f) R = 0.f;
         T(noise, i) = R - offset;
@@ -176,54 +207,41 @@ __device__ void hybridmp(const vbm_batch &b, const vbm_psy *p, int lane, const f
 
     if (fixed <= 0) return;
 
-    for (i = 0, x = 0.f; i < n; i++, x += 1.f) {
-        hi = i + fixed / 2;
-        lo = hi - fixed;
+    // fixed-width window pass (lib/psy.c:3593-3636)
+    int f1 = 0;
+    for (; f1 < n; f1++) {
+        int hi = f1 + fixed / 2, lo = hi - fixed;
         if (hi >= n) break;
         if (lo >= 0) break;
-
-        tN = T(N, hi) + T(N, -lo);
-        tX = T(X, hi) - T(X, -lo);
-        tXX = T(XX, hi) + T(XX, -lo);
-        tY = T(Y, hi) + T(Y, -lo);
-        tXY = T(XY, hi) - T(XY, -lo);
-
-        A = tY * tXX - tX * tXY;
-        B = tN * tXY - tX * tY;
-        D = tN * tXX - tX * tX;
-        R = (A + x * B) / D;
-
-        if (R - offset < T(noise, i)) T(noise, i) = R - offset;
     }
-    for (; i < n; i++, x += 1.f) {
-        hi = i + fixed / 2;
-        lo = hi - fixed;
+    int f2 = f1;
+    for (; f2 < n; f2++) {
+        int hi = f2 + fixed / 2, lo = hi - fixed;
         if (hi >= n) break;
         if (lo < 0) break;
-
-        tN = T(N, hi) - T(N, lo);
-        tX = T(X, hi) - T(X, lo);
-        tXX = T(XX, hi) - T(XX, lo);
-        tY = T(Y, hi) - T(Y, lo);
-        tXY = T(XY, hi) - T(XY, lo);
-
-        A = tY * tXX - tX * tXY;
-        B = tN * tXY - tX * tY;
-        D = tN * tXX - tX * tX;
-        R = (A + x * B) / D;
-
-        if (R - offset < T(noise, i)) T(noise, i) = R - offset;
     }
-    for (; i < n; i++, x += 1.f) {
-        R = (A + x * B) / D;
-        if (R - offset < T(noise, i)) T(noise, i) = R - offset;
+    HY_SOLVE(true, true, 0, f1)
+    HY_SOLVE(false, true, f1, f2)
+    for (i = f2; i < n; i += HY_PF) {
+        float prev[HY_PF];
+#pragma unroll
+        for (int u = 0; u < HY_PF; u++) prev[u] = (i + u < n) ? T(noise, i + u) : 0.f;
+#pragma unroll
+        for (int u = 0; u < HY_PF; u++) {
+            if (i + u < n) {
+                x = (float)(i + u);
+                R = (A + x * B) / D;
+                if (R - offset < prev[u]) T(noise, i + u) = R - offset;
+            }
+        }
     }
+#undef HY_SOLVE
 }
 
 // aoTuV M7, lib/psy.c:3645-3768.  temp/inmod: 256-entry per-lane scratch carved from seedT/ampstackT
 __device__ void ntfix(const vbm_batch &b, const vbm_psy *p, int lane, const float *spectral, float *noise)
 {
-    const int L = b.L;
+    const size_t tb = TB(b, lane);
     int i, j, k;
     int n = p->n;
     int nx = p->tonefix_end;
@@ -325,14 +343,13 @@ __global__ void k_noisemask(vbm_batch b)
 {
     const int lane = blockIdx.x * blockDim.x + threadIdx.x;
     if (lane >= b.ncb) return;
-    const int L = b.L;
+    const size_t tb = TB(b, lane);
     const vbm_setup *s = b.setup;
     const vbm_psy *p = psy_of(b);
     const int n = p->n;
     const int sb = lane / b.ch, c = lane - sb * b.ch;
     const int sid = b.stream_id[sb];
     const int col = sid * b.ch + c;
-    const int Lc = b.st.Lc;
     const int partition = (p->normal_p ? p->normal_partition : 16);
     int i, j, k;
 
@@ -435,7 +452,7 @@ __global__ void k_noisemask(vbm_batch b)
                 float temp = T(logmdct, i) - T(epeak, i);
                 T(epeak, i) = 0.f;
                 if (temp >= 12.f) {
-                    float mi = T(logmdct, i) - lastmdct[(size_t)i * Lc + col];
+                    float mi = T(logmdct, i) - lastmdct[(size_t)(col >> 6) * b.st.slab_words + (size_t)i * 64 + (col & 63)];
                     if (mi >= 1) T(epeak, i) = mi;
                 }
             }
@@ -448,7 +465,7 @@ __global__ void k_noisemask(vbm_batch b)
 __device__ void seed_curve(const vbm_batch &b, int lane, float *seed, const float *curves /*[P_LEVELS][EHMER_MAX+2]*/,
                            const float amp, const int oc, const int n, const int linesper, const float dBoffset)
 {
-    const int L = b.L;
+    const size_t tb = TB(b, lane);
     int i, post1;
     int seedptr;
     const float *posts, *curve;
@@ -475,7 +492,7 @@ __global__ void k_tonemask(vbm_batch b)
 {
     const int lane = blockIdx.x * blockDim.x + threadIdx.x;
     if (lane >= b.ncb) return;
-    const int L = b.L;
+    const size_t tb = TB(b, lane);
     const vbm_psy *p = psy_of(b);
     const int n = p->n;
     const int sb = lane / b.ch;
@@ -588,18 +605,17 @@ __global__ void k_mix(vbm_batch b)
 {
     const int lane = blockIdx.x * blockDim.x + threadIdx.x;
     if (lane >= b.ncb) return;
-    const int L = b.L;
+    const size_t tb = TB(b, lane);
     const vbm_setup *s = b.setup;
     const vbm_psy *p = psy_of(b);
     const int n = p->n;
     const int sb = lane / b.ch, c = lane - sb * b.ch;
     const int sid = b.stream_id[sb];
     const int col = sid * b.ch + c;
-    const size_t Lc = b.st.Lc;
-    float *lastmdct = b.st.mblock + col;   // element i at lastmdct[i*Lc]
-    float *tempmdct = b.st.tblock + col;
-#define LAST(i) lastmdct[(size_t)(i) * Lc]
-#define TEMP(i) tempmdct[(size_t)(i) * Lc]
+    float *lastmdct = b.st.mblock + (size_t)(col >> 6) * b.st.slab_words + (col & 63);   // element i at [i*64]
+    float *tempmdct = b.st.tblock + (size_t)(col >> 6) * b.st.slab_words + (col & 63);
+#define LAST(i) lastmdct[(size_t)(i) * 64]
+#define TEMP(i) tempmdct[(size_t)(i) * 64]
     const float *noise = b.noiseT, *tone = b.toneT;
     float *logmask = b.logmaskT, *mdct = b.mdctT, *logmdct = b.logmdctT, *npeak = b.npeakT;
     const int offset_select = 1;

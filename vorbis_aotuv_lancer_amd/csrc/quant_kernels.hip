@@ -215,7 +215,7 @@ __global__ void k_couple_quantize(vbm_batch b)
 {
     const int sb = blockIdx.x * blockDim.x + threadIdx.x;
     if (sb >= b.nsb) return;
-    const size_t L = b.L;
+    const size_t SW = b.slab_words;
     const vbm_setup *s = b.setup;
     const vbm_psy *p = &s->psy[b.block_mode];
     const vbm_map *vi = &s->map[b.W];
@@ -247,10 +247,11 @@ __global__ void k_couple_quantize(vbm_batch b)
 
     // columns of this stream-block's channels in the bin-major arrays
     const size_t col0 = (size_t)sb * ch;
-#define MD(k, x) b.mdctT[(size_t)(x) * L + col0 + (k)]
-#define EP(k, x) b.epeakT[(size_t)(x) * L + col0 + (k)]
-#define NP(k, x) b.npeakT[(size_t)(x) * L + col0 + (k)]
-#define IW(k, x) b.iworkT[(size_t)(x) * L + col0 + (k)]
+#define CT(buf, k, x) (buf)[(size_t)((col0 + (k)) >> 6) * SW + (size_t)(x) * 64 + ((col0 + (k)) & 63)]
+#define MD(k, x) CT(b.mdctT, k, x)
+#define EP(k, x) CT(b.epeakT, k, x)
+#define NP(k, x) CT(b.npeakT, k, x)
+#define IW(k, x) CT(b.iworkT, k, x)
 
     for (i = 0; i < ch; i++) nonzero[i] = b.nonzero[col0 + i];
     for (i = 0; i < ch + vi->coupling_steps; i++) acc[i] = 0.f;
@@ -290,7 +291,7 @@ __global__ void k_couple_quantize(vbm_batch b)
                 }
 
                 acc[track] = noise_normalize(p, limit, raw[k], quant[k], floor[k], res[k], nullptr, acc[track],
-                                             NP(k, pi), i, jn, &IW(k, i), L);
+                                             NP(k, pi), i, jn, &IW(k, i), 64);
             } else {
                 for (j = 0; j < jn; j++) {
                     floor[k][j] = 1e-10f;
@@ -394,7 +395,7 @@ __global__ void k_couple_quantize(vbm_batch b)
                 }
                 if (pointflag)
                     acc[track] = noise_normalize(p, limit, raw[Mi], quant[Mi], floor[Mi], res[Mi], flag[Mi], acc[track],
-                                                 NP(Mi, pi), i, jn, &IW(Mi, i), L);
+                                                 NP(Mi, pi), i, jn, &IW(Mi, i), 64);
                 track++;
             }
         }
@@ -413,6 +414,7 @@ __global__ void k_couple_quantize(vbm_batch b)
     }
     for (i = 0; i < ch; i++) b.nonzero[col0 + i] = nonzero[i];
 #undef MD
+#undef CT
 #undef EP
 #undef NP
 #undef IW

@@ -1,6 +1,6 @@
 // Layout changes between the wave-per-block transform kernels (block-major rows) and the
-// lane-per-block stage kernels (bin-major, batch.h): 64x64 tiles through LDS so that both the
-// read and the write side move whole 256-byte rows.
+// lane-per-block stage kernels (tiled bin-major, batch.h): 64x64 tiles through LDS so that both
+// the read and the write side move whole rows.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "batch.h"
@@ -8,22 +8,40 @@
 
 namespace {
 
-// src[r][c] (rows x cols, leading dimension lds) -> dst[c][r] (leading dimension ldd)
+// block-major src[c][r] (ncols blocks x rows, row length = rows) -> tiled dst:
+//   dst[(c >> 6) * slab + r * 64 + (c & 63)]
 template <typename T>
-__global__ void k_transpose(const T *__restrict__ src, T *__restrict__ dst, int rows, int cols, size_t lds,
-                            size_t ldd)
+__global__ void k_to_tiled(const T *__restrict__ src, T *__restrict__ dst, int ncols, int rows, size_t slab)
 {
     __shared__ T tile[64][65];
-    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 256 threads: 4 rows per pass
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 256 threads
+    for (int cc = ty; cc < 64; cc += 4) {
+        int c = c0 + cc, r = r0 + tx;
+        tile[cc][tx] = (c < ncols && r < rows) ? src[(size_t)c * rows + r] : T(0);
+    }
+    __syncthreads();
     for (int rr = ty; rr < 64; rr += 4) {
         int r = r0 + rr, c = c0 + tx;
-        tile[rr][tx] = (r < rows && c < cols) ? src[(size_t)r * lds + c] : T(0);
+        if (r < rows && c < ncols) dst[(size_t)(c >> 6) * slab + (size_t)r * 64 + (c & 63)] = tile[tx][rr];
+    }
+}
+
+// tiled src -> block-major dst[c][r]
+template <typename T>
+__global__ void k_from_tiled(const T *__restrict__ src, T *__restrict__ dst, int ncols, int rows, size_t slab)
+{
+    __shared__ T tile[64][65];
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int rr = ty; rr < 64; rr += 4) {
+        int r = r0 + rr, c = c0 + tx;
+        tile[rr][tx] = (r < rows && c < ncols) ? src[(size_t)(c >> 6) * slab + (size_t)r * 64 + (c & 63)] : T(0);
     }
     __syncthreads();
     for (int cc = ty; cc < 64; cc += 4) {
         int c = c0 + cc, r = r0 + tx;
-        if (c < cols && r < rows) dst[(size_t)c * ldd + r] = tile[tx][cc];
+        if (c < ncols && r < rows) dst[(size_t)c * rows + r] = tile[tx][cc];
     }
 }
 
@@ -34,10 +52,18 @@ __global__ void k_spread_flags(const uint8_t *__restrict__ wflags, uint8_t *__re
 }
 
 template <typename T>
-int transpose(const T *src, T *dst, int rows, int cols, size_t lds, size_t ldd, hipStream_t st)
+int to_tiled(const T *src, T *dst, int ncols, int rows, size_t slab, hipStream_t st)
 {
-    dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64));
-    hipLaunchKernelGGL(k_transpose<T>, grid, dim3(256), 0, st, src, dst, rows, cols, lds, ldd);
+    dim3 grid((unsigned)((ncols + 63) / 64), (unsigned)((rows + 63) / 64));
+    hipLaunchKernelGGL(k_to_tiled<T>, grid, dim3(256), 0, st, src, dst, ncols, rows, slab);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+template <typename T>
+int from_tiled(const T *src, T *dst, int ncols, int rows, size_t slab, hipStream_t st)
+{
+    dim3 grid((unsigned)((ncols + 63) / 64), (unsigned)((rows + 63) / 64));
+    hipLaunchKernelGGL(k_from_tiled<T>, grid, dim3(256), 0, st, src, dst, ncols, rows, slab);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -52,21 +78,23 @@ extern "C" int vbm_launch_spread_flags(const vbm_batch *b, hipStream_t st)
 
 extern "C" int vbm_launch_transpose_in(const vbm_batch *b, hipStream_t st)
 {
-    // [ncb][n] block-major -> [n][L] bin-major
-    int rc = transpose<float>(b->mdct_bm, b->mdctT, b->ncb, b->n, (size_t)b->n, (size_t)b->L, st);
+    int rc = to_tiled<float>(b->mdct_bm, b->mdctT, b->ncb, b->n, b->slab_words, st);
     if (rc) return rc;
-    return transpose<float>(b->logfft_bm, b->logfftT, b->ncb, b->n, (size_t)b->n, (size_t)b->L, st);
+    return to_tiled<float>(b->logfft_bm, b->logfftT, b->ncb, b->n, b->slab_words, st);
 }
 
-extern "C" int vbm_launch_untranspose_f32(const float *srcT, float *dst_bm, int rows, int L, int ncb, hipStream_t st)
+extern "C" int vbm_launch_untranspose_f32(const float *srcT, float *dst_bm, int rows, size_t slab, int ncols,
+                                          hipStream_t st)
 {
-    return transpose<float>(srcT, dst_bm, rows, ncb, (size_t)L, (size_t)rows, st);
+    return from_tiled<float>(srcT, dst_bm, ncols, rows, slab, st);
 }
-extern "C" int vbm_launch_untranspose_i32(const int *srcT, int *dst_bm, int rows, int L, int ncb, hipStream_t st)
+extern "C" int vbm_launch_untranspose_i32(const int *srcT, int *dst_bm, int rows, size_t slab, int ncols,
+                                          hipStream_t st)
 {
-    return transpose<int>(srcT, dst_bm, rows, ncb, (size_t)L, (size_t)rows, st);
+    return from_tiled<int>(srcT, dst_bm, ncols, rows, slab, st);
 }
-extern "C" int vbm_launch_untranspose_u8(const uint8_t *srcT, uint8_t *dst_bm, int rows, int L, int ncb, hipStream_t st)
+extern "C" int vbm_launch_untranspose_u8(const uint8_t *srcT, uint8_t *dst_bm, int rows, size_t slab, int ncols,
+                                         hipStream_t st)
 {
-    return transpose<uint8_t>(srcT, dst_bm, rows, ncb, (size_t)L, (size_t)rows, st);
+    return from_tiled<uint8_t>(srcT, dst_bm, ncols, rows, slab, st);
 }
