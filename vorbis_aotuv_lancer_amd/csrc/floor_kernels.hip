@@ -46,7 +46,7 @@ __device__ __forceinline__ int dBquant(float x)
     return i;
 }
 
-__device__ int fit_line(const lsfit_acc *a, int fits, int *y0, int *y1, const vbm_floor *info)
+__device__ __forceinline__ int fit_line(const lsfit_acc *a, int fits, int *y0, int *y1, const vbm_floor *info)
 {
     double xb = 0, yb = 0, x2b = 0, y2b = 0, xyb = 0, bn = 0;
     int i;

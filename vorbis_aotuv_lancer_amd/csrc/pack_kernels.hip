@@ -66,7 +66,7 @@ __device__ __forceinline__ int book_encode(const vbm_book *bk, int a, BitW &w)
 }
 
 // local_book_besterror (lib/res0.c:316-378); a[] is the vector (dim <= 8) in registers
-__device__ int besterror(const vbm_book *book, int *a)
+__device__ __forceinline__ int besterror(const vbm_book *book, int *a)
 {
     const int dim = book->dim;
     int i, j, o;
@@ -114,7 +114,7 @@ __device__ int besterror(const vbm_book *book, int *a)
 }
 
 // _01forward over `nvec` channel vectors; vec[j] + x*stride[j] addresses sample x of vector j
-__device__ void forward01(BitW &w, const vbm_setup *s, const vbm_residue *info, int *const *vec, const size_t *stride,
+__device__ __forceinline__ void forward01(BitW &w, const vbm_setup *s, const vbm_residue *info, int *const *vec, const size_t *stride,
                           int nvec, const int *partword, size_t pw_stride, int pw_rows)
 {
 #define PW(j, i) partword[((size_t)(j) * pw_rows + (i)) * pw_stride]

@@ -95,7 +95,7 @@ __global__ void k_prologue(vbm_batch b)
 // table-only conditions, so their limits are lane-uniform.
 #define HY_PF 8
 #define HY_SB 4
-__device__ void hybridmp(const vbm_batch &b, const vbm_psy *p, int lane, const float *__restrict__ f,
+__device__ __forceinline__ void hybridmp(const vbm_batch &b, const vbm_psy *p, int lane, const float *__restrict__ f,
                          float *__restrict__ noise, const float offset, const int fixed)
 {
     const size_t tb = TB(b, lane);
@@ -123,7 +123,7 @@ __device__ void hybridmp(const vbm_batch &b, const vbm_psy *p, int lane, const f
     for (i = 1, x = 1.f; i < n; i += HY_PF) {
         float fv[HY_PF];
 #pragma unroll
-        for (int u = 0; u < HY_PF; u++) fv[u] = (i + u < n) ? T(f, i + u) : 0.f;
+        for (int u = 0; u < HY_PF; u++) fv[u] = T(f, (i + u < n) ? i + u : n - 1);   // unconditional, clamped
 #pragma unroll
         for (int u = 0; u < HY_PF; u++) {
             if (i + u < n) {
@@ -159,17 +159,18 @@ __device__ void hybridmp(const vbm_batch &b, const vbm_psy *p, int lane, const f
     for (i = (I0); i < (I1); i += HY_SB) {                                                                      \
         float e[HY_SB][10], prev[HY_SB];                                                                        \
         _Pragma("unroll") for (int u = 0; u < HY_SB; u++) {                                                     \
-            if (i + u < (I1)) {                                                                                 \
+            {                                                                                                   \
+                const int ii = (i + u < (I1)) ? i + u : (I1) - 1;   /* clamped: loads stay unconditional */     \
                 int lo, hi;                                                                                     \
-                if (FIXEDPASS) { hi = i + u + fixed / 2; lo = hi - fixed; }                                     \
-                else { lo = p->bark_lo[i + u]; hi = p->bark_hi[i + u]; }                                        \
+                if (FIXEDPASS) { hi = ii + fixed / 2; lo = hi - fixed; }                                        \
+                else { lo = p->bark_lo[ii]; hi = p->bark_hi[ii]; }                                              \
                 int lo_ = MIRROR ? -lo : lo;                                                                    \
                 e[u][0] = T(N, hi);  e[u][1] = T(N, lo_);                                                       \
                 e[u][2] = T(X, hi);  e[u][3] = T(X, lo_);                                                       \
                 e[u][4] = T(XX, hi); e[u][5] = T(XX, lo_);                                                      \
                 e[u][6] = T(Y, hi);  e[u][7] = T(Y, lo_);                                                       \
                 e[u][8] = T(XY, hi); e[u][9] = T(XY, lo_);                                                      \
-                if (FIXEDPASS) prev[u] = T(noise, i + u);                                                       \
+                if (FIXEDPASS) prev[u] = T(noise, ii);                                                          \
             }                                                                                                   \
         }                                                                                                       \
         _Pragma("unroll") for (int u = 0; u < HY_SB; u++) {                                                     \
@@ -225,7 +226,7 @@ __device__ void hybridmp(const vbm_batch &b, const vbm_psy *p, int lane, const f
     for (i = f2; i < n; i += HY_PF) {
         float prev[HY_PF];
 #pragma unroll
-        for (int u = 0; u < HY_PF; u++) prev[u] = (i + u < n) ? T(noise, i + u) : 0.f;
+        for (int u = 0; u < HY_PF; u++) prev[u] = T(noise, (i + u < n) ? i + u : n - 1);
 #pragma unroll
         for (int u = 0; u < HY_PF; u++) {
             if (i + u < n) {
@@ -239,7 +240,7 @@ __device__ void hybridmp(const vbm_batch &b, const vbm_psy *p, int lane, const f
 }
 
 // aoTuV M7, lib/psy.c:3645-3768.  temp/inmod: 256-entry per-lane scratch carved from seedT/ampstackT
-__device__ void ntfix(const vbm_batch &b, const vbm_psy *p, int lane, const float *spectral, float *noise)
+__device__ __forceinline__ void ntfix(const vbm_batch &b, const vbm_psy *p, int lane, const float *spectral, float *noise)
 {
     const size_t tb = TB(b, lane);
     int i, j, k;
@@ -462,7 +463,7 @@ __global__ void k_noisemask(vbm_batch b)
 }
 
 // ---------------------------------------------------------------------------------------------
-__device__ void seed_curve(const vbm_batch &b, int lane, float *seed, const float *curves /*[P_LEVELS][EHMER_MAX+2]*/,
+__device__ __forceinline__ void seed_curve(const vbm_batch &b, int lane, float *seed, const float *curves /*[P_LEVELS][EHMER_MAX+2]*/,
                            const float amp, const int oc, const int n, const int linesper, const float dBoffset)
 {
     const size_t tb = TB(b, lane);

@@ -19,7 +19,7 @@
 
 namespace {
 
-__device__ void flag_lossless(int limit, float prepoint, float postpoint, float prepoint_r, float postpoint_r,
+__device__ __forceinline__ void flag_lossless(int limit, float prepoint, float postpoint, float prepoint_r, float postpoint_r,
                               float *res, const float *mdct, const float *enpeak, const float *floor, int *flag,
                               int i, int jn)
 {
@@ -109,7 +109,7 @@ __device__ __forceinline__ float min_indemnity_dipole_hypot(const float a, const
 }
 
 // q / out / r / res / f / flags are this channel's partition scratch; out is strided (bin-major)
-__device__ float noise_normalize(const vbm_psy *p, const int limit, float *r, float *q, const float *f, float *res,
+__device__ __forceinline__ float noise_normalize(const vbm_psy *p, const int limit, float *r, float *q, const float *f, float *res,
                                  const int *flags, float acc, const float nepeak, const int i, const int n,
                                  int *out, const size_t ostride)
 {
