@@ -87,156 +87,194 @@ __global__ void k_prologue(vbm_batch b)
 }
 
 // ---------------------------------------------------------------------------------------------
-// bark_noise_hybridmp, lib/psy.c:3480-3638.  f / noise are bin-major columns of this lane.
-// The five prefix sums are strictly sequential per lane (source order); to keep the lane from
-// stalling on every element, loads are issued in batches ahead of the dependent arithmetic
-// (the input column for the prefix pass, the ten window-edge sums for the solve passes).
-// The three solve phases of the source (mirrored window / plain window / tail) are bounded by
-// table-only conditions, so their limits are lane-uniform.
-#define HY_PF 8
-#define HY_SB 4
-__device__ __forceinline__ void hybridmp(const vbm_batch &b, const vbm_psy *p, int lane, const float *__restrict__ f,
-                         float *__restrict__ noise, const float offset, const int fixed)
+// _vp_noisemask is split into launches so that only what the source's float arithmetic forces to
+// be serial stays serial:
+//   k_nm_prefix<PASS>  the five running sums N, X, XX, Y, XY of bark_noise_hybridmp
+//                      (lib/psy.c:3480-3541).  Each sum is an order-bound chain over the bins, but
+//                      the five chains are independent of one another: blockIdx.y picks the chain,
+//                      so a tile of 64 channel-blocks is walked by five wavefronts.  PASS 1 also
+//                      produces logmdct (lib/mapping0.c:936-950) and lb_loudnoise_fix.
+//   k_nm_solve<PASS>   the per-bin regression solve (lib/psy.c:3543-3636): every bin only reads the
+//                      finished sums, so bins are sliced over blockIdx.y.
+//   k_nm_ntfix         aoTuV M7 (short and transition blocks only), serial over <= 256 bins.
+//   k_nm_post          compander, M2 post-echo, M8, M9: independent per normal-partition, sliced
+//                      over blockIdx.y in units of partitions.
+#define HY_PF 16
+
+struct hy_bounds { int i1, i2, f1, f2; };
+
+// phase limits of the solve loops: table-only conditions, evaluated by the host (setup_host.cpp)
+__device__ __forceinline__ hy_bounds hybrid_bounds(const vbm_psy *p, int fixed)
 {
-    const size_t tb = TB(b, lane);
+    hy_bounds h;
+    h.i1 = p->hy_i1; h.i2 = p->hy_i2;
+    h.f1 = (fixed > 0) ? p->hy_f1 : 0;
+    h.f2 = (fixed > 0) ? p->hy_f2 : 0;
+    return h;
+}
+
+template <int PASS, int CHAIN>
+__device__ __forceinline__ void prefix_chain(const vbm_batch &b, const vbm_psy *p, const size_t tb, const int sid, const int col)
+{
     const int n = p->n;
-    float *__restrict__ N = b.sumT;
-    float *__restrict__ X = b.sumT + (size_t)n * 64;
-    float *__restrict__ XX = b.sumT + (size_t)2 * n * 64;
-    float *__restrict__ Y = b.sumT + (size_t)3 * n * 64;
-    float *__restrict__ XY = b.sumT + (size_t)4 * n * 64;
-    float tN, tX, tXX, tY, tXY;
-    int i;
-    float R = 0.f, A = 0.f, B = 0.f, D = 1.f;
-    float w, x, y;
+    const float offset = (PASS == 1) ? 140.f : 0.f;
+    const float *__restrict__ src = (PASS == 1) ? b.mdctT : b.workT;
+    float *__restrict__ dst = b.sumT + (size_t)CHAIN * n * 64;
+    float *__restrict__ logmdct = b.logmdctT;
+    float acc = 0.f, x = 0.f;
+    double hi_th = 0;
+    const int n25p = p->n25p, n75p = p->n75p;
 
-    tN = tX = tXX = tY = tXY = 0.f;
-
-    y = T(f, 0) + offset;
-    if (y < 1.f) y = 1.f;
-    w = (float)((double)(y * y) * .5);
-    tN += w;
-    tX += w;
-    tY += w * y;
-    T(N, 0) = tN; T(X, 0) = tX; T(XX, 0) = tXX; T(Y, 0) = tY; T(XY, 0) = tXY;
-
-    for (i = 1, x = 1.f; i < n; i += HY_PF) {
+    for (int i = 0; i < n; i += HY_PF) {
         float fv[HY_PF];
 #pragma unroll
-        for (int u = 0; u < HY_PF; u++) fv[u] = T(f, (i + u < n) ? i + u : n - 1);   // unconditional, clamped
+        for (int u = 0; u < HY_PF; u++) fv[u] = T(src, (i + u < n) ? i + u : n - 1);   // unconditional, clamped
 #pragma unroll
         for (int u = 0; u < HY_PF; u++) {
             if (i + u < n) {
-                y = fv[u] + offset;
+                float v = fv[u];
+                if (PASS == 1) {
+                    v = (float)((double)vbm_todB(v) + .345);   // logmdct, lib/mapping0.c:936
+                    if (CHAIN == 0) {
+                        T(logmdct, i + u) = v;
+                        if (i + u >= n25p && i + u < n75p) hi_th += (v > -130) ? (double)v : -130.;
+                    }
+                }
+                float y = v + offset;
                 if (y < 1.f) y = 1.f;
-                w = y * y;
-                tN += w;
-                tX += w * x;
-                tXX += w * x * x;
-                tY += w * y;
-                tXY += w * x * y;
-                T(N, i + u) = tN; T(X, i + u) = tX; T(XX, i + u) = tXX; T(Y, i + u) = tY; T(XY, i + u) = tXY;
+                float w = y * y;
+                if (i + u == 0) {
+                    // first element, lib/psy.c:3497-3507: half weight, x = 0 (X takes w, XX and XY nothing)
+                    w = (float)((double)w * .5);
+                    if (CHAIN == 0 || CHAIN == 1) acc += w;
+                    if (CHAIN == 3) acc += w * y;
+                } else {
+                    if (CHAIN == 0) acc += w;
+                    if (CHAIN == 1) acc += w * x;
+                    if (CHAIN == 2) acc += w * x * x;
+                    if (CHAIN == 3) acc += w * y;
+                    if (CHAIN == 4) acc += w * x * y;
+                }
+                T(dst, i + u) = acc;
                 x += 1.f;
             }
         }
     }
 
-    // phase limits (lib/psy.c:3543-3544, :3565-3566), identical in every lane
-    int i1 = 0;
-    for (; i1 < n; i1++) {
-        int lo = p->bark_lo[i1], hi = p->bark_hi[i1];
-        if (lo >= 0 || -lo >= n) break;
-        if (hi >= n) break;
+    if (PASS == 1 && CHAIN == 0) {
+        // lb_loudnoise_fix (lib/psy.c:5152-5180)
+        float noise_compand_level = b.st.lowcomp[col];
+        const int lW_block_mode = b.st.lW_block_mode[sid];
+        if (p->m_val < 0.5) noise_compand_level = -1;
+        else if (p->normal_thresh > .45) noise_compand_level = -1;
+        else if ((b.block_mode == 2 && lW_block_mode == 3) || (b.block_mode == 3 && lW_block_mode == 2)) {
+            hi_th /= n;
+            if (hi_th > -40.) noise_compand_level = -1;
+            else if (hi_th < -50.) noise_compand_level = 1.f;
+            else noise_compand_level = (float)(1. - ((hi_th + 50) / 10));
+        }
+        b.st.lowcomp[col] = noise_compand_level;
     }
-    int i2 = i1;
-    for (; i2 < n; i2++) {
-        int lo = p->bark_lo[i2], hi = p->bark_hi[i2];
-        if (lo < 0 || lo >= n) break;
-        if (hi >= n) break;
+}
+
+template <int PASS>
+__global__ void k_nm_prefix(vbm_batch b)
+{
+    const int lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= b.ncb) return;
+    const size_t tb = TB(b, lane);
+    const vbm_psy *p = psy_of(b);
+    const int sb = lane / b.ch, c = lane - sb * b.ch;
+    const int sid = b.stream_id[sb];
+    const int col = sid * b.ch + c;
+    switch (blockIdx.y) {
+    case 0: prefix_chain<PASS, 0>(b, p, tb, sid, col); break;
+    case 1: prefix_chain<PASS, 1>(b, p, tb, sid, col); break;
+    case 2: prefix_chain<PASS, 2>(b, p, tb, sid, col); break;
+    case 3: prefix_chain<PASS, 3>(b, p, tb, sid, col); break;
+    default: prefix_chain<PASS, 4>(b, p, tb, sid, col); break;
+    }
+}
+
+// window sums and the regression terms of one bin (lib/psy.c:3549-3560 mirrored, :3571-3582 plain)
+struct hy_abd { float A, B, D; };
+__device__ __forceinline__ hy_abd hybrid_abd(const float *__restrict__ sum, const size_t tb, const int n, const int lo,
+                                             const int hi, const bool mirror)
+{
+    const float *__restrict__ N = sum;
+    const float *__restrict__ X = sum + (size_t)n * 64;
+    const float *__restrict__ XX = sum + (size_t)2 * n * 64;
+    const float *__restrict__ Y = sum + (size_t)3 * n * 64;
+    const float *__restrict__ XY = sum + (size_t)4 * n * 64;
+    const int lo_ = mirror ? -lo : lo;
+    const float nh = T(N, hi), nl = T(N, lo_), xh = T(X, hi), xl = T(X, lo_), xxh = T(XX, hi), xxl = T(XX, lo_);
+    const float yh = T(Y, hi), yl = T(Y, lo_), xyh = T(XY, hi), xyl = T(XY, lo_);
+    float tN, tX, tXX, tY, tXY;
+    if (mirror) {
+        tN = nh + nl; tX = xh - xl; tXX = xxh + xxl; tY = yh + yl; tXY = xyh - xyl;
+    } else {
+        tN = nh - nl; tX = xh - xl; tXX = xxh - xxl; tY = yh - yl; tXY = xyh - xyl;
+    }
+    hy_abd r;
+    r.A = tY * tXX - tX * tXY;
+    r.B = tN * tXY - tX * tY;
+    r.D = tN * tXX - tX * tX;
+    return r;
+}
+
+template <int PASS>
+__global__ void k_nm_solve(vbm_batch b, int nchunks)
+{
+    const int lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= b.ncb) return;
+    const size_t tb = TB(b, lane);
+    const vbm_psy *p = psy_of(b);
+    const int n = p->n;
+    const int c0 = (int)((long)n * blockIdx.y / nchunks), c1 = (int)((long)n * (blockIdx.y + 1) / nchunks);
+    const float offset = (PASS == 1) ? 140.f : 0.f;
+    const int fixed = (PASS == 1) ? -1 : p->noisewindowfixed;
+    const hy_bounds h = hybrid_bounds(p, fixed);
+    const float *__restrict__ sum = b.sumT;
+    float *__restrict__ noise = b.noiseT;
+    float *__restrict__ work = b.workT;
+    const float *__restrict__ logmdct = b.logmdctT;
+
+    // the tail loops (lib/psy.c:3587-3591, :3631-3635) keep A, B, D of the last bin solved before them
+    hy_abd tail; tail.A = 0.f; tail.B = 0.f; tail.D = 1.f;
+    if (c1 > h.i2 && h.i2 > 0) {
+        const int t = h.i2 - 1;
+        tail = hybrid_abd(sum, tb, n, p->bark_lo[t], p->bark_hi[t], t < h.i1);
+    }
+    hy_abd ftail = tail;
+    if (fixed > 0 && c1 > h.f2 && h.f2 > 0) {
+        const int t = h.f2 - 1, hi = t + fixed / 2, lo = hi - fixed;
+        ftail = hybrid_abd(sum, tb, n, lo, hi, t < h.f1);
     }
 
-#define HY_SOLVE(MIRROR, FIXEDPASS, I0, I1)                                                                    \
-    for (i = (I0); i < (I1); i += HY_SB) {                                                                      \
-        float e[HY_SB][10], prev[HY_SB];                                                                        \
-        _Pragma("unroll") for (int u = 0; u < HY_SB; u++) {                                                     \
-            {                                                                                                   \
-                const int ii = (i + u < (I1)) ? i + u : (I1) - 1;   /* clamped: loads stay unconditional */     \
-                int lo, hi;                                                                                     \
-                if (FIXEDPASS) { hi = ii + fixed / 2; lo = hi - fixed; }                                        \
-                else { lo = p->bark_lo[ii]; hi = p->bark_hi[ii]; }                                              \
-                int lo_ = MIRROR ? -lo : lo;                                                                    \
-                e[u][0] = T(N, hi);  e[u][1] = T(N, lo_);                                                       \
-                e[u][2] = T(X, hi);  e[u][3] = T(X, lo_);                                                       \
-                e[u][4] = T(XX, hi); e[u][5] = T(XX, lo_);                                                      \
-                e[u][6] = T(Y, hi);  e[u][7] = T(Y, lo_);                                                       \
-                e[u][8] = T(XY, hi); e[u][9] = T(XY, lo_);                                                      \
-                if (FIXEDPASS) prev[u] = T(noise, ii);                                                          \
-            }                                                                                                   \
-        }                                                                                                       \
-        _Pragma("unroll") for (int u = 0; u < HY_SB; u++) {                                                     \
-            if (i + u < (I1)) {                                                                                 \
-                x = (float)(i + u);                                                                             \
-                if (MIRROR) {                                                                                   \
-                    tN = e[u][0] + e[u][1]; tX = e[u][2] - e[u][3]; tXX = e[u][4] + e[u][5];                    \
-                    tY = e[u][6] + e[u][7]; tXY = e[u][8] - e[u][9];                                            \
-                } else {                                                                                        \
-                    tN = e[u][0] - e[u][1]; tX = e[u][2] - e[u][3]; tXX = e[u][4] - e[u][5];                    \
-                    tY = e[u][6] - e[u][7]; tXY = e[u][8] - e[u][9];                                            \
-                }                                                                                               \
-                A = tY * tXX - tX * tXY;                                                                        \
-                B = tN * tXY - tX * tY;                                                                         \
-                D = tN * tXX - tX * tX;                                                                         \
-                R = (A + x * B) / D;                                                                            \
-                if (FIXEDPASS) {                                                                                \
-                    if (R - offset < prev[u]) T(noise, i + u) = R - offset;                                     \
-                } else {                                                                                        \
-                    if (R < 0.f) R = 0.f;                                                                       \
-                    T(noise, i + u) = R - offset;                                                               \
-                }                                                                                               \
-            }                                                                                                   \
-        }                                                                                                       \
-    }
-
-    HY_SOLVE(true, false, 0, i1)
-    HY_SOLVE(false, false, i1, i2)
-    for (i = i2; i < n; i++) {   // x is exactly (float)i in the source as well (x += 1.f from 0, i < 2^24)
-        x = (float)i;
-        R = (A + x * B) / D;
+    for (int i = c0; i < c1; i++) {
+        const float x = (float)i;   // the source's x += 1.f from 0 is exact below 2^24
+        hy_abd v = tail;
+        if (i < h.i2) v = hybrid_abd(sum, tb, n, p->bark_lo[i], p->bark_hi[i], i < h.i1);
+        float R = (v.A + x * v.B) / v.D;
         if (R < 0.f) R = 0.f;
-        T(noise, i) = R - offset;
-    }
-
-    if (fixed <= 0) return;
-
-    // fixed-width window pass (lib/psy.c:3593-3636)
-    int f1 = 0;
-    for (; f1 < n; f1++) {
-        int hi = f1 + fixed / 2, lo = hi - fixed;
-        if (hi >= n) break;
-        if (lo >= 0) break;
-    }
-    int f2 = f1;
-    for (; f2 < n; f2++) {
-        int hi = f2 + fixed / 2, lo = hi - fixed;
-        if (hi >= n) break;
-        if (lo < 0) break;
-    }
-    HY_SOLVE(true, true, 0, f1)
-    HY_SOLVE(false, true, f1, f2)
-    for (i = f2; i < n; i += HY_PF) {
-        float prev[HY_PF];
-#pragma unroll
-        for (int u = 0; u < HY_PF; u++) prev[u] = T(noise, (i + u < n) ? i + u : n - 1);
-#pragma unroll
-        for (int u = 0; u < HY_PF; u++) {
-            if (i + u < n) {
-                x = (float)(i + u);
-                R = (A + x * B) / D;
-                if (R - offset < prev[u]) T(noise, i + u) = R - offset;
+        float nz = R - offset;
+        if (PASS == 1) {
+            T(noise, i) = nz;
+            T(work, i) = T(logmdct, i) - nz;                    // lib/psy.c:3807
+        } else {
+            if (fixed > 0) {
+                hy_abd w = ftail;
+                if (i < h.f2) {
+                    const int hi = i + fixed / 2, lo = hi - fixed;
+                    w = hybrid_abd(sum, tb, n, lo, hi, i < h.f1);
+                }
+                R = (w.A + x * w.B) / w.D;
+                if (R - offset < nz) nz = R - offset;
             }
+            T(noise, i) = nz;
+            T(work, i) = T(logmdct, i) - T(work, i);            // lib/psy.c:3812
         }
     }
-#undef HY_SOLVE
 }
 
 // aoTuV M7, lib/psy.c:3645-3768.  temp/inmod: 256-entry per-lane scratch carved from seedT/ampstackT
@@ -340,7 +378,14 @@ __device__ __forceinline__ void ntfix(const vbm_batch &b, const vbm_psy *p, int 
     }
 }
 
-__global__ void k_noisemask(vbm_batch b)
+__global__ void k_nm_ntfix(vbm_batch b)
+{
+    const int lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= b.ncb) return;
+    ntfix(b, psy_of(b), lane, b.logmdctT, b.workT);
+}
+
+__global__ void k_nm_post(vbm_batch b, int nchunks)
 {
     const int lane = blockIdx.x * blockDim.x + threadIdx.x;
     if (lane >= b.ncb) return;
@@ -352,71 +397,37 @@ __global__ void k_noisemask(vbm_batch b)
     const int sid = b.stream_id[sb];
     const int col = sid * b.ch + c;
     const int partition = (p->normal_p ? p->normal_partition : 16);
+    const int nparts = (n + partition - 1) / partition;
+    const int k0 = (int)((long)nparts * blockIdx.y / nchunks), k1 = (int)((long)nparts * (blockIdx.y + 1) / nchunks);
+    const int c0 = k0 * partition, c1 = VMIN(k1 * partition, n);
     int i, j, k;
 
     float *logmdct = b.logmdctT, *logmask = b.noiseT, *work = b.workT, *epeak = b.epeakT, *npeak = b.npeakT;
-
-    // logmdct[j] = todB(mdct[j]) + .345   (lib/mapping0.c:936)
-    for (i = 0; i < n; i++) T(logmdct, i) = (float)((double)vbm_todB(T(b.mdctT, i)) + .345);
-
-    // lb_loudnoise_fix (lib/psy.c:5152-5180)
-    float noise_compand_level = b.st.lowcomp[col];
-    {
-        const int lW_block_mode = b.st.lW_block_mode[sid];
-        if (p->m_val < 0.5) noise_compand_level = -1;
-        else if (p->normal_thresh > .45) noise_compand_level = -1;
-        else if ((b.block_mode == 2 && lW_block_mode == 3) || (b.block_mode == 3 && lW_block_mode == 2)) {
-            double hi_th = 0;
-            for (i = p->n25p; i < p->n75p; i++) {
-                float v = T(logmdct, i);
-                if (v > -130) hi_th += v;
-                else hi_th += -130;
-            }
-            hi_th /= n;
-            if (hi_th > -40.) noise_compand_level = -1;
-            else if (hi_th < -50.) noise_compand_level = 1.f;
-            else noise_compand_level = (float)(1. - ((hi_th + 50) / 10));
-        }
-        b.st.lowcomp[col] = noise_compand_level;
-    }
-
-    hybridmp(b, p, lane, logmdct, logmask, 140.f, -1);
-
-    for (i = 0; i < n; i++) T(work, i) = T(logmdct, i) - T(logmask, i);
-
-    hybridmp(b, p, lane, work, logmask, 0.f, p->noisewindowfixed);
-
-    for (i = 0; i < n; i++) T(work, i) = T(logmdct, i) - T(work, i);
-
-    ntfix(b, p, lane, logmdct, work);
+    const float noise_compand_level = b.st.lowcomp[col];
 
     // noise compand & aoTuV M5 extension & pre-store tone peak
-    i = 0;
-    if (noise_compand_level > 0) {
-        int thter = p->n33p;
-        for (; i < thter; i++) {
+    {
+        const int thter = (noise_compand_level > 0) ? p->n33p : 0;
+        for (i = c0; i < c1; i++) {
             int dB = (int)((double)T(logmask, i) + .5);
             if (dB >= VBM_NOISE_COMPAND_LEVELS) dB = VBM_NOISE_COMPAND_LEVELS - 1;
             if (dB < 0) dB = 0;
-            T(epeak, i) = T(work, i) + s->stn_compand[dB];
-            T(logmask, i) = T(work, i) + p->noisecompand[dB] -
-                            ((p->noisecompand[dB] - p->noisecompand_high[dB]) * noise_compand_level);
+            const float wv = T(work, i);
+            T(epeak, i) = wv + s->stn_compand[dB];
+            if (i < thter)
+                T(logmask, i) = wv + p->noisecompand[dB] -
+                                ((p->noisecompand[dB] - p->noisecompand_high[dB]) * noise_compand_level);
+            else
+                T(logmask, i) = wv + p->noisecompand[dB];
         }
     }
-    for (; i < n; i++) {
-        int dB = (int)((double)T(logmask, i) + .5);
-        if (dB >= VBM_NOISE_COMPAND_LEVELS) dB = VBM_NOISE_COMPAND_LEVELS - 1;
-        if (dB < 0) dB = 0;
-        T(epeak, i) = T(work, i) + s->stn_compand[dB];
-        T(logmask, i) = T(work, i) + p->noisecompand[dB];
-    }
 
-    for (i = 0, k = 0; i < n; i += partition, k++) T(npeak, k) = 0.f;
+    for (k = k0; k < k1; k++) T(npeak, k) = 0.f;
 
     // reduction of post-echo (postprocessing of aoTuV M2)
     const float poste = b.poste[lane];
     if (poste > 0) {
-        for (i = 0, k = 0; i < p->min_nn_lp; i += partition, k++) {
+        for (k = k0, i = c0; k < k1 && i < p->min_nn_lp; i += partition, k++) {
             float temp = VMIN(VMIN(poste, 30.f), p->noiseoffset[1][i] + 30.f);
             if (temp <= 0) continue;
             T(npeak, k) = -1.f;
@@ -425,7 +436,7 @@ __global__ void k_noisemask(vbm_batch b)
     }
 
     // M8
-    for (k = 0, i = 0; i < p->min_nn_lp; i += partition, k++) {
+    for (k = k0, i = c0; k < k1 && i < p->min_nn_lp; i += partition, k++) {
         const float nt = 4;
         float o = p->noiseoffset[1][i + partition - 1] + 6;
         float me = 0;
@@ -446,50 +457,53 @@ __global__ void k_noisemask(vbm_batch b)
 
     // M9
     {
-        i = 0;
-        if (b.block_mode > 1) {
-            const float *lastmdct = b.st.mblock;
-            for (; i < p->tonecomp_endp; i++) {
+        const float *lastmdct = b.st.mblock;
+        const int m9_end = (b.block_mode > 1) ? p->tonecomp_endp : 0;
+        for (i = c0; i < c1; i++) {
+            float e = 0.f;
+            if (i < m9_end) {
                 float temp = T(logmdct, i) - T(epeak, i);
-                T(epeak, i) = 0.f;
                 if (temp >= 12.f) {
                     float mi = T(logmdct, i) - lastmdct[(size_t)(col >> 6) * b.st.slab_words + (size_t)i * 64 + (col & 63)];
-                    if (mi >= 1) T(epeak, i) = mi;
+                    if (mi >= 1) e = mi;
                 }
             }
+            T(epeak, i) = e;
         }
-        for (; i < n; i++) T(epeak, i) = 0.f;
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void seed_curve(const vbm_batch &b, int lane, float *seed, const float *curves /*[P_LEVELS][EHMER_MAX+2]*/,
-                           const float amp, const int oc, const int n, const int linesper, const float dBoffset)
+// _vp_tonemask in four launches:
+//   k_tm_init    seed[] = NEGINF                                            (sliced over seed lines)
+//   k_tm_stamp   seed_loop: every group of bins stamps its masking curve into seed[] with a
+//                maximum.  max is order-free, so groups are sliced over blockIdx.y and the stamp is
+//                an integer atomicMax on an order-preserving key of the float.
+//   k_tm_chase   max_seeds part 1 = seed_chase (lib/psy.c:773-934): a data-driven stack walk, serial
+//                per lane; the two stack entries the walk looks at live in registers.
+//   k_tm_apply   max_seeds part 2: per bin, the minimum of its seed-line segment raises the ATH
+//                floor (segments precomputed by the host: vbm_psy.seg_p0/seg_p1).  Sliced over bins.
+__device__ __forceinline__ int seed_key(float f)
 {
+    int v = __float_as_int(f);
+    return v ^ ((v >> 31) & 0x7fffffff);   // monotone float -> int (involution)
+}
+__device__ __forceinline__ float seed_val(int k) { return __int_as_float(k ^ ((k >> 31) & 0x7fffffff)); }
+
+__global__ void k_tm_init(vbm_batch b, int nchunks)
+{
+    const int lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= b.ncb) return;
     const size_t tb = TB(b, lane);
-    int i, post1;
-    int seedptr;
-    const float *posts, *curve;
-
-    int choice = (int)(((double)(amp + dBoffset) - 30.) * (double).1f);   // (amp+dBoffset-P_LEVEL_0)*.1f, P_LEVEL_0 = 30. (double)
-    choice = VMAX(choice, 0);
-    choice = VMIN(choice, VBM_P_LEVELS - 1);
-    posts = curves + choice * (VBM_EHMER_MAX + 2);
-    curve = posts + 2;
-    post1 = (int)posts[1];
-    seedptr = (int)((float)oc + (posts[0] - VBM_EHMER_OFFSET) * linesper - (linesper >> 1));
-
-    for (i = (int)posts[0]; i < post1; i++) {
-        if (seedptr > 0) {
-            float lin = amp + curve[i];
-            if (T(seed, seedptr) < lin) T(seed, seedptr) = lin;
-        }
-        seedptr += linesper;
-        if (seedptr >= n) break;
-    }
+    const vbm_psy *p = psy_of(b);
+    const int tn = p->total_octave_lines;
+    const int c0 = (int)((long)tn * blockIdx.y / nchunks), c1 = (int)((long)tn * (blockIdx.y + 1) / nchunks);
+    int *seed = (int *)b.seedT;
+    const int k = seed_key(NEGINF);
+    for (int i = c0; i < c1; i++) T(seed, i) = k;
 }
 
-__global__ void k_tonemask(vbm_batch b)
+__global__ void k_tm_stamp(vbm_batch b, int nchunks)
 {
     const int lane = blockIdx.x * blockDim.x + threadIdx.x;
     if (lane >= b.ncb) return;
@@ -497,101 +511,168 @@ __global__ void k_tonemask(vbm_batch b)
     const vbm_psy *p = psy_of(b);
     const int n = p->n;
     const int sb = lane / b.ch;
-    float *seed = b.seedT, *ampstack = b.ampstackT;
-    int *posstack = b.posstackT;
+    int *seed = (int *)b.seedT;
     const float *f = b.logfftT;
-    float *flr = b.toneT;
-    long i;
+    const int g0 = (int)((long)p->ngroups * blockIdx.y / nchunks), g1 = (int)((long)p->ngroups * (blockIdx.y + 1) / nchunks);
 
     const float global_specmax = b.global_ampmax[sb];
     const float local_specmax = b.local_ampmax[lane];
-
     float att = local_specmax + p->ath_adjatt;
-    for (i = 0; i < p->total_octave_lines; i++) T(seed, i) = NEGINF;
     if (att < p->ath_maxatt) att = p->ath_maxatt;
-    for (i = 0; i < n; i++) T(flr, i) = p->ath[i] + att;
+    const float dBoffset = p->max_curve_dB - global_specmax;
+    const int tn = p->total_octave_lines, linesper = p->eighth_octave_lines;
 
-    // seed_loop (lib/psy.c:719-771)
-    {
-        float dBoffset = p->max_curve_dB - global_specmax;
-        for (i = 0; i < n; i++) {
-            float max = T(f, i);
-            long oc = p->octave[i];
-            while (i + 1 < n && p->octave[i + 1] == oc) {
-                i++;
-                if (T(f, i) > max) max = T(f, i);
-            }
-            if (max + 6.f > T(flr, i)) {
-                oc = oc >> p->shiftoc;
-                if (oc >= VBM_P_BANDS) oc = VBM_P_BANDS - 1;
-                if (oc < 0) oc = 0;
-                seed_curve(b, lane, seed, p->tonecurves + (size_t)oc * VBM_P_LEVELS * (VBM_EHMER_MAX + 2), max,
-                           p->octave[i] - p->firstoc, p->total_octave_lines, p->eighth_octave_lines, dBoffset);
+    // seed_loop (lib/psy.c:719-771), seed_curve (:652-717)
+    for (int g = g0; g < g1; g++) {
+        const int s0 = p->group_start[g], s1 = p->group_start[g + 1];
+        float max = T(f, s0);
+        for (int i = s0 + 1; i < s1; i++) {
+            float v = T(f, i);
+            if (v > max) max = v;
+        }
+        const int last = s1 - 1;
+        if (max + 6.f > p->ath[last] + att) {
+            long oc = p->octave[last];
+            oc = oc >> p->shiftoc;
+            if (oc >= VBM_P_BANDS) oc = VBM_P_BANDS - 1;
+            if (oc < 0) oc = 0;
+            const float *curves = p->tonecurves + (size_t)oc * VBM_P_LEVELS * (VBM_EHMER_MAX + 2);
+            const int ocl = p->octave[last] - p->firstoc;
+            int choice = (int)(((double)(max + dBoffset) - 30.) * (double).1f);   // P_LEVEL_0 = 30. (double)
+            choice = VMAX(choice, 0);
+            choice = VMIN(choice, VBM_P_LEVELS - 1);
+            const float *posts = curves + choice * (VBM_EHMER_MAX + 2);
+            const float *curve = posts + 2;
+            const int post1 = (int)posts[1];
+            int seedptr = (int)((float)ocl + (posts[0] - VBM_EHMER_OFFSET) * linesper - (linesper >> 1));
+            for (int i = (int)posts[0]; i < post1; i++) {
+                if (seedptr > 0) atomicMax(&T(seed, seedptr), seed_key(max + curve[i]));
+                seedptr += linesper;
+                if (seedptr >= tn) break;
             }
         }
     }
+}
 
-    // max_seeds (lib/psy.c:936-1085) with seed_chase (:773-934)
-    {
-        const long tn = p->total_octave_lines;
-        const int linesper = p->eighth_octave_lines;
-        long stack = 0, pos = 0;
-        for (i = 0; i < tn; i++) {
-            if (stack < 2) {
-                T(posstack, stack) = (int)i;
-                T(ampstack, stack++) = T(seed, i);
-            } else {
-                while (1) {
-                    if (T(seed, i) < T(ampstack, stack - 1)) {
-                        T(posstack, stack) = (int)i;
-                        T(ampstack, stack++) = T(seed, i);
-                        break;
-                    } else {
-                        if (i < T(posstack, stack - 1) + linesper) {
-                            if (stack > 1 && T(ampstack, stack - 1) <= T(ampstack, stack - 2) &&
-                                i < T(posstack, stack - 2) + linesper) {
-                                stack--;
-                                continue;
+__global__ void k_tm_chase(vbm_batch b)
+{
+    const int lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= b.ncb) return;
+    const size_t tb = TB(b, lane);
+    const vbm_psy *p = psy_of(b);
+    float *seed = b.seedT, *ampstack = b.ampstackT;
+    const int *seedk = (const int *)b.seedT;
+    int *posstack = b.posstackT;
+    const int tn = p->total_octave_lines;
+    const int linesper = p->eighth_octave_lines;
+
+    // seed_chase, lib/psy.c:773-934.  (a1,p1) is the stack top, (a2,p2) the entry below it.
+    int stack = 0;
+    float a1 = 0.f, a2 = 0.f;
+    int p1 = 0, p2 = 0;
+#define TM_PUSH(ii, v)                                            \
+    {                                                             \
+        T(posstack, stack) = (ii);                                \
+        T(ampstack, stack) = (v);                                 \
+        stack++;                                                  \
+        a2 = a1; p2 = p1; a1 = (v); p1 = (ii);                    \
+    }
+    for (int i = 0; i < tn; i += 8) {
+        int kv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) kv[u] = T(seedk, (i + u < tn) ? i + u : tn - 1);
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int ii = i + u;
+            if (ii < tn) {
+                const float v = seed_val(kv[u]);
+                if (stack < 2) {
+                    TM_PUSH(ii, v)
+                } else {
+                    while (1) {
+                        if (v < a1) {
+                            TM_PUSH(ii, v)
+                            break;
+                        } else {
+                            if (ii < p1 + linesper) {
+                                if (stack > 1 && a1 <= a2 && ii < p2 + linesper) {
+                                    stack--;
+                                    a1 = a2; p1 = p2;
+                                    if (stack >= 2) {
+                                        a2 = T(ampstack, stack - 2);
+                                        p2 = T(posstack, stack - 2);
+                                    }
+                                    continue;
+                                }
                             }
+                            TM_PUSH(ii, v)
+                            break;
                         }
-                        T(posstack, stack) = (int)i;
-                        T(ampstack, stack++) = T(seed, i);
-                        break;
                     }
                 }
             }
         }
-        for (i = 0; i < stack; i++) {
-            long endpos;
-            if (i < stack - 1 && T(ampstack, i + 1) > T(ampstack, i)) {
-                endpos = T(posstack, i + 1);
-            } else {
-                endpos = T(posstack, i) + linesper + 1;
-            }
-            if (endpos > tn) endpos = tn;
-            for (; pos < endpos; pos++) T(seed, pos) = T(ampstack, i);
-        }
+    }
+#undef TM_PUSH
 
-        long linpos = 0;
-        pos = p->octave[0] - p->firstoc - (linesper >> 1);
-        while (linpos + 1 < n) {
-            float minV = T(seed, pos);
-            long end = ((p->octave[linpos] + p->octave[linpos + 1]) >> 1) - p->firstoc;
-            if (minV > p->tone_abs_limit) minV = p->tone_abs_limit;
-            while (pos + 1 <= end) {
-                pos++;
-                float sv = T(seed, pos);
-                if ((sv > NEGINF && sv < minV) || minV == NEGINF) minV = sv;
+    // the fill (lib/psy.c:1012-1026), walked by seed line so the stores stay row-coalesced: entry e
+    // covers lines up to endpos(e); entries whose endpos is already behind fill nothing
+    {
+        int e = 0;
+        float amp = T(ampstack, 0), ampn = (stack > 1) ? T(ampstack, 1) : 0.f;
+        int endpos;
+        if (0 < stack - 1 && ampn > amp) endpos = T(posstack, 1);
+        else endpos = T(posstack, 0) + linesper + 1;
+        if (endpos > tn) endpos = tn;
+        for (int pos = 0; pos < tn; pos++) {
+            while (pos >= endpos && e + 1 < stack) {
+                e++;
+                amp = ampn;
+                ampn = (e < stack - 1) ? T(ampstack, e + 1) : 0.f;
+                if (e < stack - 1 && ampn > amp) endpos = T(posstack, e + 1);
+                else endpos = T(posstack, e) + linesper + 1;
+                if (endpos > tn) endpos = tn;
             }
-            end = pos + p->firstoc;
-            for (; linpos < n && p->octave[linpos] <= end; linpos++)
-                if (T(flr, linpos) < minV) T(flr, linpos) = minV;
+            T(seed, pos) = amp;
         }
-        {
-            float minV = T(seed, tn - 1);
-            for (; linpos < n; linpos++)
-                if (T(flr, linpos) < minV) T(flr, linpos) = minV;
+    }
+}
+
+__global__ void k_tm_apply(vbm_batch b, int nchunks)
+{
+    const int lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= b.ncb) return;
+    const size_t tb = TB(b, lane);
+    const vbm_psy *p = psy_of(b);
+    const int n = p->n;
+    const int c0 = (int)((long)n * blockIdx.y / nchunks), c1 = (int)((long)n * (blockIdx.y + 1) / nchunks);
+    const float *seed = b.seedT;
+    float *flr = b.toneT;
+    const int tn = p->total_octave_lines;
+
+    float att = b.local_ampmax[lane] + p->ath_adjatt;
+    if (att < p->ath_maxatt) att = p->ath_maxatt;
+
+    int q0 = -2, q1 = -2;
+    float minV = 0.f;
+    for (int i = c0; i < c1; i++) {
+        const int p0 = p->seg_p0[i], p1 = p->seg_p1[i];
+        if (p0 != q0 || p1 != q1) {
+            q0 = p0; q1 = p1;
+            if (p0 < 0) {
+                minV = T(seed, tn - 1);
+            } else {
+                minV = T(seed, p0);
+                if (minV > p->tone_abs_limit) minV = p->tone_abs_limit;
+                for (int pos = p0 + 1; pos <= p1; pos++) {
+                    float sv = T(seed, pos);
+                    if ((sv > NEGINF && sv < minV) || minV == NEGINF) minV = sv;
+                }
+            }
         }
+        float v = p->ath[i] + att;
+        if (v < minV) v = minV;
+        T(flr, i) = v;
     }
 }
 
@@ -602,7 +683,10 @@ struct mod3 {
     float noise_rate, noise_rate_low, noise_center, tone_rate;
 };
 
-__global__ void k_mix(vbm_batch b)
+// Bins are independent for every block type except impulse short blocks (M3 reads and rewrites
+// tempmdct across bins and updates npeak per partition in bin order), so the launch splits the
+// bin range into `nchunks` slices (blockIdx.y) for block modes 1..3 and uses one slice for mode 0.
+__global__ void k_mix(vbm_batch b, int nchunks)
 {
     const int lane = blockIdx.x * blockDim.x + threadIdx.x;
     if (lane >= b.ncb) return;
@@ -610,6 +694,7 @@ __global__ void k_mix(vbm_batch b)
     const vbm_setup *s = b.setup;
     const vbm_psy *p = psy_of(b);
     const int n = p->n;
+    const int i0 = (int)((long)n * blockIdx.y / nchunks), i1 = (int)((long)n * (blockIdx.y + 1) / nchunks);
     const int sb = lane / b.ch, c = lane - sb * b.ch;
     const int sid = b.stream_id[sb];
     const int col = sid * b.ch + c;
@@ -731,7 +816,7 @@ __global__ void k_mix(vbm_batch b)
         if (p->normal_thresh > 1.) m4_start = 9999;
     }
 
-    for (i = 0; i < n; i++) {
+    for (i = i0; i < i1; i++) {
         float val = T(noise, i) + p->noiseoffset[offset_select][i];
         float tval = T(tone, i) + toneatt;
         const float lm = T(logmdct, i);
@@ -824,16 +909,16 @@ __global__ void k_mix(vbm_batch b)
         case 0:
         case 1:
             if (nW_modenumber) {
-                for (i = 0, k = 0; i < n; i++, k += mag)
+                for (i = i0, k = i0 * mag; i < i1; i++, k += mag)
                     for (j = 0; j < mag; j++) LAST(k + j) = T(logmdct, i);
             } else {
-                for (i = 0; i < n; i++) LAST(i) = T(logmdct, i);
+                for (i = i0; i < i1; i++) LAST(i) = T(logmdct, i);
             }
             break;
         case 2:
             if (!nW_modenumber) {
                 int nsh = n >> 3;
-                for (i = 0; i < nsh; i++) {
+                for (i = i0; i < i1 && i < nsh; i++) {
                     int ni = i * mag;
                     float v = T(logmdct, ni);
                     for (j = 1; j < mag; j++)
@@ -841,11 +926,11 @@ __global__ void k_mix(vbm_batch b)
                     LAST(i) = v;
                 }
             } else {
-                for (i = 0; i < n; i++) LAST(i) = T(logmdct, i);
+                for (i = i0; i < i1; i++) LAST(i) = T(logmdct, i);
             }
             break;
         case 3:
-            for (i = 0; i < n; i++) LAST(i) = T(logmdct, i);
+            for (i = i0; i < i1; i++) LAST(i) = T(logmdct, i);
             break;
         default:
             break;
@@ -858,6 +943,8 @@ __global__ void k_mix(vbm_batch b)
 }  // namespace
 
 static inline dim3 grid_for(int lanes) { return dim3((unsigned)((lanes + 63) / 64)); }
+// slices of the bin range for the kernels whose bins are independent (long blocks: 64 bins each)
+static inline int bin_chunks(const vbm_batch *b) { return b->n >= 1024 ? 16 : 2; }
 
 extern "C" int vbm_launch_prologue(const vbm_batch *b, hipStream_t st)
 {
@@ -866,16 +953,29 @@ extern "C" int vbm_launch_prologue(const vbm_batch *b, hipStream_t st)
 }
 extern "C" int vbm_launch_noisemask(const vbm_batch *b, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_noisemask, grid_for(b->ncb), dim3(64), 0, st, *b);
+    const unsigned tiles = (unsigned)((b->ncb + 63) / 64);
+    const int nchunks = bin_chunks(b);
+    hipLaunchKernelGGL(k_nm_prefix<1>, dim3(tiles, 5), dim3(64), 0, st, *b);
+    hipLaunchKernelGGL(k_nm_solve<1>, dim3(tiles, (unsigned)nchunks), dim3(64), 0, st, *b, nchunks);
+    hipLaunchKernelGGL(k_nm_prefix<2>, dim3(tiles, 5), dim3(64), 0, st, *b);
+    hipLaunchKernelGGL(k_nm_solve<2>, dim3(tiles, (unsigned)nchunks), dim3(64), 0, st, *b, nchunks);
+    if (b->block_mode <= 2) hipLaunchKernelGGL(k_nm_ntfix, dim3(tiles), dim3(64), 0, st, *b);
+    hipLaunchKernelGGL(k_nm_post, dim3(tiles, (unsigned)nchunks), dim3(64), 0, st, *b, nchunks);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 extern "C" int vbm_launch_tonemask(const vbm_batch *b, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_tonemask, grid_for(b->ncb), dim3(64), 0, st, *b);
+    const unsigned tiles = (unsigned)((b->ncb + 63) / 64);
+    const int nchunks = bin_chunks(b);
+    hipLaunchKernelGGL(k_tm_init, dim3(tiles, (unsigned)nchunks), dim3(64), 0, st, *b, nchunks);
+    hipLaunchKernelGGL(k_tm_stamp, dim3(tiles, (unsigned)nchunks), dim3(64), 0, st, *b, nchunks);
+    hipLaunchKernelGGL(k_tm_chase, dim3(tiles), dim3(64), 0, st, *b);
+    hipLaunchKernelGGL(k_tm_apply, dim3(tiles, (unsigned)nchunks), dim3(64), 0, st, *b, nchunks);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 extern "C" int vbm_launch_mix(const vbm_batch *b, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_mix, grid_for(b->ncb), dim3(64), 0, st, *b);
+    const int nchunks = (b->block_mode == 0) ? 1 : bin_chunks(b);
+    hipLaunchKernelGGL(k_mix, dim3((unsigned)((b->ncb + 63) / 64), (unsigned)nchunks), dim3(64), 0, st, *b, nchunks);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

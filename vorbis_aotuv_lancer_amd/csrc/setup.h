@@ -42,12 +42,19 @@ struct vbm_psy {                 // vorbis_info_psy + vorbis_look_psy
     float tonecomp_thres;
     int min_nn_lp, tonefix_end;
     int n25p, n33p, n75p;
+    int hy_i1, hy_i2;                // bark_noise_hybridmp phase limits, variable window (lib/psy.c:3543, :3565)
+    int hy_f1, hy_f2;                // same for the fixed window of noisewindowfixed (:3595, :3614); 0 if unused
     const float *tonecurves;         // [P_BANDS][P_LEVELS][EHMER_MAX+2]
     const float *noiseoffset[VBM_P_NOISECURVES];  // n each
     const float *ath;                // n
     const int *octave;               // n
     const int *bark_lo, *bark_hi;    // n each: lib/psy.c:471 packs ((lo-1)<<16)+(hi-1); kept unpacked-as-read
     const float *ntfix_noiseoffset;  // n
+    // table-only loop structure of _vp_tonemask, unrolled by the host so the device can slice it:
+    int ngroups;                     // runs of equal octave[] (the inner while of seed_loop, lib/psy.c:737-743)
+    const int *group_start;          // ngroups+1 bins, last = n
+    const int *seg_p0, *seg_p1;      // n each: seed lines [p0..p1] whose minimum max_seeds applies to the bin
+                                     //   (lib/psy.c:1045-1076); p0 = -1 for the bins of the final tail (:1078-1084)
 };
 
 struct vbm_floor {               // vorbis_info_floor1 + vorbis_look_floor1

@@ -177,7 +177,7 @@ void tone_curves(const float *ATH, const float *tonemasks /*[17][6][56]*/, std::
 
 struct PsyTables {
     std::vector<float> tonecurves, ath, ntfix, noiseoffset[VBM_P_NOISECURVES];
-    std::vector<int> octave, bark_lo, bark_hi;
+    std::vector<int> octave, bark_lo, bark_hi, group_start, seg_p0, seg_p1;
 };
 
 // lib/psy.c:352-507
@@ -273,6 +273,31 @@ void psy_look(vbm_psy &p, PsyTables &t, const Pack &common, int eighth_octave_li
     for (long i = 0; i < n; i++) {
         double a = (double)((float)i + .25f) * .5 * (double)rate / (double)n;
         t.octave[i] = (int)(long)(toOC_d(a) * (double)(1 << (shiftoc + 1)) + (double).5f);
+    }
+
+    // seed_loop groups bins that share an octave line; max_seeds walks seed lines and bins together
+    // under table-only conditions.  Both walks are recorded here.
+    for (long i = 0; i < n; i++)
+        if (i == 0 || t.octave[i] != t.octave[i - 1]) t.group_start.push_back((int)i);
+    p.ngroups = (int)t.group_start.size();
+    t.group_start.push_back(n);
+    t.seg_p0.assign(n, -1);
+    t.seg_p1.assign(n, -1);
+    {
+        const long linesper = eighth_octave_lines;
+        long linpos = 0, pos = t.octave[0] - p.firstoc - (linesper >> 1);
+        while (linpos + 1 < n) {
+            const long p0 = pos, before = linpos;
+            long end = ((t.octave[linpos] + t.octave[linpos + 1]) >> 1) - p.firstoc;
+            while (pos + 1 <= end) pos++;
+            end = pos + p.firstoc;
+            for (; linpos < n && t.octave[linpos] <= end; linpos++) {
+                t.seg_p0[linpos] = (int)p0;
+                t.seg_p1[linpos] = (int)pos;
+            }
+            if (linpos == before || p0 < 0 || pos >= p.total_octave_lines)
+                throw std::string("psy_look: max_seeds walk leaves the seed array");
+        }
     }
 
     tone_curves(ATH, tonemasks, t.tonecurves, p.toneatt, (float)((double)rate * .5 / (double)n), n,
@@ -422,6 +447,9 @@ static void rebase_setup(vbm_setup &s, const unsigned char *base)
         rebase(p.octave, base);
         rebase(p.bark_lo, base);
         rebase(p.bark_hi, base);
+        rebase(p.group_start, base);
+        rebase(p.seg_p0, base);
+        rebase(p.seg_p1, base);
         rebase(p.ntfix_noiseoffset, base);
     }
     rebase(s.book, base);
@@ -607,6 +635,40 @@ vbm_setup_host *vbm_setup_host_load(const char *common_path, const char *mode_pa
             p.bark_lo = as_off<int>(A.put(t.bark_lo));
             p.bark_hi = as_off<int>(A.put(t.bark_hi));
             p.ntfix_noiseoffset = as_off<float>(A.put(t.ntfix));
+            p.group_start = as_off<int>(A.put(t.group_start));
+            p.seg_p0 = as_off<int>(A.put(t.seg_p0));
+            p.seg_p1 = as_off<int>(A.put(t.seg_p1));
+            {   // loop limits of bark_noise_hybridmp: table-only conditions, evaluated once here
+                const int n = p.n, fixed = p.noisewindowfixed;
+                int k = 0;
+                for (; k < n; k++) {
+                    int lo = t.bark_lo[k], hi = t.bark_hi[k];
+                    if (lo >= 0 || -lo >= n) break;
+                    if (hi >= n) break;
+                }
+                p.hy_i1 = k;
+                for (; k < n; k++) {
+                    int lo = t.bark_lo[k], hi = t.bark_hi[k];
+                    if (lo < 0 || lo >= n) break;
+                    if (hi >= n) break;
+                }
+                p.hy_i2 = k;
+                p.hy_f1 = p.hy_f2 = 0;
+                if (fixed > 0) {
+                    for (k = 0; k < n; k++) {
+                        int hi = k + fixed / 2, lo = hi - fixed;
+                        if (hi >= n) break;
+                        if (lo >= 0) break;
+                    }
+                    p.hy_f1 = k;
+                    for (; k < n; k++) {
+                        int hi = k + fixed / 2, lo = hi - fixed;
+                        if (hi >= n) break;
+                        if (lo < 0) break;
+                    }
+                    p.hy_f2 = k;
+                }
+            }
         }
 
         // ---- static tables
