@@ -68,9 +68,18 @@ struct vbm_batch {
     // stream-block lanes (leading dimension Ls)
     int *partwordT;                 // [max partvals][Ls * max bundle]
     int *workvqT;                   // [ch*n][Ls]  interleaved residue vector of res2 (lib/res0.c:781-787)
-    uint8_t *packetT;               // [max_packet_bytes][Ls]  byte-major packet buffers
+    float *m6defT;                  // [partitions][coupling steps][Ls]  aoTuV M6 temp_def per partition (-1: none)
+    int couple_parallel;            // coupling steps use disjoint channels: partitions may run sliced
+    int couple_parts, couple_m6parts;  // partitions below the lowpass / those in the M6 range
+    int *vqlenT, *vqoffT;           // [stages][ch][max partvals][Ls]  bits / bit offset of every residue run
+    uint64_t *vqcodeT;              // [stages][ch*n][64] per tile of `vq_slab_words` 8-byte words: code | len << 32
+    size_t vq_slab_words;
+    uint8_t *packetT;               // [max_packet_bytes/4 words][64] per tile: little-endian 32-bit packet words
     int *packet_bytes;              // [Ls]
-    int max_packet_bytes;
+    int *packet_bits;               // [Ls]  write position while the packet is assembled
+    int max_packet_bytes;           // multiple of 4
+    int pack_submaps;               // residue submaps of this block type and their partition counts (host copy)
+    int pack_partvals[16];
 };
 
 #ifdef __HIPCC__

@@ -154,12 +154,26 @@ extern "C" int vbm_encoder_create(vbm_encoder **out, vbm_setup_handle *setup, in
 
         size_t srows = 0;
         auto stake = [&](size_t r) { size_t at = srows; srows += r; return at * 64; };
-        const size_t o_pw = stake((size_t)e->max_partvals * e->ch), o_vq = stake((size_t)nmax * e->ch);
+        int max_steps = 1;
+        for (int i = 0; i < s->modes && i < 2; i++)
+            if (s->map[i].coupling_steps > max_steps) max_steps = s->map[i].coupling_steps;
+        const size_t o_pw = stake((size_t)e->max_partvals * e->ch), o_vq = stake((size_t)nmax * e->ch),
+                     o_m6 = stake((size_t)(nmax / 8 + 1) * max_steps);
+        int max_stages = 1;
+        for (int i = 0; i < s->residues; i++)
+            if (s->residue[i].stages > max_stages) max_stages = s->residue[i].stages;
+        const size_t o_len = stake((size_t)max_stages * e->ch * e->max_partvals),
+                     o_off = stake((size_t)max_stages * e->ch * e->max_partvals);
         b.sb_slab_words = srows * 64;
         int *sslab;
         A(sslab, int, (Ls / 64) * b.sb_slab_words);
         b.partwordT = sslab + o_pw;
         b.workvqT = sslab + o_vq;
+        b.m6defT = (float *)(sslab + o_m6);
+        b.vqlenT = sslab + o_len;
+        b.vqoffT = sslab + o_off;
+        b.vq_slab_words = (size_t)max_stages * nmax * e->ch * 64;
+        A(b.vqcodeT, uint64_t, (Ls / 64) * b.vq_slab_words);
     }
     A(b.poste, float, L);
     A(b.global_ampmax, float, Ls);
@@ -167,6 +181,7 @@ extern "C" int vbm_encoder_create(vbm_encoder **out, vbm_setup_handle *setup, in
     A(b.nonzero, int, L);
     A(b.packetT, uint8_t, Ls * (size_t)e->max_packet_bytes);   // [sb>>6][max_packet_bytes][64]
     A(b.packet_bytes, int, Ls);
+    A(b.packet_bits, int, Ls);
 #undef A
     b.stream_id = e->d_stream_id;
     b.wflags = e->d_wflags;
@@ -204,6 +219,31 @@ static void configure(vbm_encoder *e, vbm_batch &b, int block_mode, int nsb, con
     b.L = e->L;      // fixed leading dimensions: buffers were sized for `cap`
     b.Ls = e->Ls;
     b.pcm = d_pcm;
+    {
+        // partition slicing of couple/quantise (quant_kernels.hip): allowed when no channel takes part
+        // in two coupling steps; lowpass rounding as lib/mapping0.c:778-781
+        const vbm_map &m = s->map[b.W];
+        const vbm_psy &p = s->psy[block_mode];
+        unsigned seen = 0;
+        b.couple_parallel = 1;
+        for (int i = 0; i < m.coupling_steps; i++) {
+            unsigned bits = (1u << m.coupling_mag[i]) | (1u << m.coupling_ang[i]);
+            if (seen & bits) b.couple_parallel = 0;
+            seen |= bits;
+        }
+        const int partition = p.normal_p ? p.normal_partition : 16;
+        int lowpassr = s->block_lowpassr[b.W ? 1 : 0];
+        if (lowpassr % p.normal_partition) lowpassr = (lowpassr / p.normal_partition + 1) * p.normal_partition;
+        b.couple_parts = (lowpassr + partition - 1) / partition;
+        int m6end = p.tonefix_end < lowpassr ? p.tonefix_end : lowpassr;
+        b.couple_m6parts = m.coupling_steps ? (m6end + partition - 1) / partition : 0;
+        if (b.couple_parts > b.n / 8 + 1) b.couple_parallel = 0;   // table rows were sized for partitions >= 8 bins
+        b.pack_submaps = m.submaps;
+        for (int i = 0; i < m.submaps && i < 16; i++) {
+            const vbm_residue &r = s->residue[m.residuesubmap[i]];
+            b.pack_partvals[i] = (r.end - r.begin) / r.grouping;
+        }
+    }
 }
 
 extern "C" int vbm_analysis_batch(vbm_encoder *e, int block_mode, int nsb, const int *stream_ids,
@@ -213,7 +253,7 @@ extern "C" int vbm_analysis_batch(vbm_encoder *e, int block_mode, int nsb, const
     if (!e || block_mode < 0 || block_mode > 3 || nsb < 0 || nsb > e->cap) return VBM_EINVAL;
     if (nsb == 0) return VBM_OK;
     if (!stream_ids || !wflags || !d_pcm) return VBM_EINVAL;
-    if ((uintptr_t)d_pcm & 15) return VBM_EINVAL;
+    if (((uintptr_t)d_pcm & 15) || ((uintptr_t)d_packets & 3)) return VBM_EINVAL;
     const vbm_setup *s = e->hs;
     if (s->modes < 2 && (block_mode >> 1)) return VBM_EINVAL;
     for (int i = 0; i < nsb; i++)
@@ -267,9 +307,9 @@ extern "C" int vbm_analysis_batch(vbm_encoder *e, int block_mode, int nsb, const
     MARK();
     RUN(vbm_launch_pack(&b, st));
     MARK();
-    if (d_packets)
-        RUN(vbm_launch_untranspose_u8(b.packetT, d_packets, e->max_packet_bytes, (size_t)e->max_packet_bytes * 64,
-                                      nsb, st));
+    if (d_packets)   // word-major tiles -> [nsb][max_packet_bytes] bytes (little-endian words)
+        RUN(vbm_launch_untranspose_i32((const int *)b.packetT, (int *)d_packets, e->max_packet_bytes / 4,
+                                       (size_t)(e->max_packet_bytes / 4) * 64, nsb, st));
     if (d_packet_bytes) {
         if ((err = hipMemcpyAsync(d_packet_bytes, b.packet_bytes, nsb * sizeof(int), hipMemcpyDeviceToDevice, st)) != hipSuccess)
             return vbm_set_hip_error(err, "hipMemcpyAsync(packet_bytes)");

@@ -1,16 +1,28 @@
-// Packet assembly for gfx950 — one lane per stream-block: header bits, floor-1 entropy coding,
-// residue classification, cascaded lattice-VQ encode and the aoTuV block-state update.
+// Packet assembly for gfx950: header bits, floor-1 entropy coding, residue classification,
+// cascaded lattice-VQ encode and the aoTuV block-state update, one lane per stream-block.
 //
-//   k_pack   mapping0_forward loop C (reference lib/mapping0.c:1204-1313) for the VBR blob:
-//            packet type / mode / window bits :1211-1218; floor1_encode's bit emission
-//            (lib/floor1.c:856-942); res*_class (_01class lib/res0.c:406-468, _2class :473-526);
-//            res*_forward -> _01forward :528-640 -> _encodepart :384-404 ->
-//            local_book_besterror :316-378 -> vorbis_book_encode (lib/codebook.c:402-410);
-//            block-state update :1297-1305.
-// Bits are appended LSb first (libogg oggpack semantics) into byte-major packet buffers
-// packetT[byte][Ls]; packet_bytes[sb] = oggpack_bytes().  The nearest-codeword search walks
-// the compact list of used entries (ascending entry order, so the reference's lowest-index
-// tie rule holds) instead of stepping the lattice odometer through unused entries.
+// mapping0_forward loop C (reference lib/mapping0.c:1204-1313) for the VBR blob, as launches:
+//   k_pack_head     packet type / mode / window bits :1211-1218; floor1_encode's bit emission
+//                   (lib/floor1.c:856-942); nonzero[] propagation over the coupling steps
+//                   (lib/psy.c:5133-5140); block-state update :1297-1305.  Serial, short.
+//   per residue submap (lib/mapping0.c:1273-1295):
+//   k_res_class     res*_class (_01class lib/res0.c:406-468, _2class :473-526) and the res2
+//                   interleave (:781-787), sliced over partitions
+//   k_res_vq        the cascade of _01forward (:528-640): _encodepart :384-404 ->
+//                   local_book_besterror :316-378.  A partition's stages only touch that
+//                   partition's samples, so partitions are sliced over blockIdx.y; every codeword
+//                   goes to a scratch slot (code | length << 32) and the partition's bit count per
+//                   stage to lenT.
+//   k_res_offsets   walks _01forward's emission order (stage, partition word, [phrase codeword],
+//                   partition, vector) over the bit counts: integer prefix sum -> bit offset of
+//                   every (stage, partition, vector) run; emits the phrase codewords.  Serial, short.
+//   k_res_emit      ORs every run into the packet at its offset (sliced over partitions).
+// Bits are appended LSb first (libogg oggpack semantics).  Packet buffers are 32-bit-word-major
+// tiles packetT[word][64 lanes], zeroed before k_pack_head; runs written by different wavefronts
+// meet inside words, hence atomicOr.  packet_bytes[sb] = oggpack_bytes(), or -1 on overflow.
+// The nearest-codeword search walks the compact list of used entries (ascending entry order,
+// so the reference's lowest-index tie rule holds) instead of stepping the lattice odometer
+// through unused entries.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "batch.h"
@@ -18,14 +30,12 @@
 
 namespace {
 
+// append-only writer of the head kernel (the lane owns its packet exclusively at that point)
 struct BitW {
-    uint8_t *base;     // &packetT[lane]
-    size_t stride;     // 64 (tiled layout)
-    int nbytes;
-    int maxbytes;
+    uint32_t *base;    // &packet words [0][lane], row stride 64
+    int nwords, maxwords;
     uint64_t acc;
     int nbits;
-    int overflow;
 };
 
 __device__ __forceinline__ void bw_write(BitW &w, uint32_t value, int bits)
@@ -34,23 +44,30 @@ __device__ __forceinline__ void bw_write(BitW &w, uint32_t value, int bits)
     if (bits < 32) value &= (1u << bits) - 1u;
     w.acc |= (uint64_t)value << w.nbits;
     w.nbits += bits;
-    while (w.nbits >= 8) {
-        if (w.nbytes < w.maxbytes) w.base[(size_t)w.nbytes * w.stride] = (uint8_t)(w.acc & 0xff);
-        else w.overflow = 1;
-        w.acc >>= 8;
-        w.nbits -= 8;
-        w.nbytes++;
+    if (w.nbits >= 32) {
+        if (w.nwords < w.maxwords) w.base[(size_t)w.nwords * 64] = (uint32_t)w.acc;
+        w.acc >>= 32;
+        w.nbits -= 32;
+        w.nwords++;
     }
 }
 
+// returns the bit position after the last bit written
 __device__ __forceinline__ int bw_finish(BitW &w)
 {
-    int total = w.nbytes + (w.nbits + 7) / 8;
-    if (w.nbits > 0) {
-        if (w.nbytes < w.maxbytes) w.base[(size_t)w.nbytes * w.stride] = (uint8_t)(w.acc & 0xff);
-        else w.overflow = 1;
-    }
-    return total;
+    if (w.nbits > 0 && w.nwords < w.maxwords) w.base[(size_t)w.nwords * 64] = (uint32_t)w.acc;
+    return w.nwords * 32 + w.nbits;
+}
+
+// OR `bits` low bits of `value` into the packet at bit position `pos`
+__device__ __forceinline__ void or_bits(uint32_t *words, int maxwords, int pos, uint32_t value, int bits)
+{
+    if (bits <= 0) return;
+    if (bits < 32) value &= (1u << bits) - 1u;
+    const uint64_t v = (uint64_t)value << (pos & 31);
+    const int wi = pos >> 5;
+    if (wi < maxwords) atomicOr(&words[(size_t)wi * 64], (uint32_t)v);
+    if ((v >> 32) && wi + 1 < maxwords) atomicOr(&words[(size_t)(wi + 1) * 64], (uint32_t)(v >> 32));
 }
 
 __device__ __forceinline__ int ilog(uint32_t v)
@@ -113,82 +130,69 @@ __device__ __forceinline__ int besterror(const vbm_book *book, int *a)
     return index;
 }
 
-// _01forward over `nvec` channel vectors; vec[j] + x*stride[j] addresses sample x of vector j
-__device__ __forceinline__ void forward01(BitW &w, const vbm_setup *s, const vbm_residue *info, int *const *vec, const size_t *stride,
-                          int nvec, const int *partword, size_t pw_stride, int pw_rows)
+// which channels of submap `sm` take part, and the residue's vector shape
+struct res_view {
+    const vbm_residue *r;
+    int nb;                       // channels in the submap
+    int chlist[VBM_MAXCH];
+    int used;                     // vectors that are coded (res2: 0 or 1; res0/1: nonzero channels)
+    int vch[VBM_MAXCH];           // res0/1: channel of vector j
+    int partvals, spp;
+};
+
+__device__ __forceinline__ res_view residue_view(const vbm_batch &b, const vbm_map *info, int sm, size_t col0)
 {
-#define PW(j, i) partword[((size_t)(j) * pw_rows + (i)) * pw_stride]
-    const int samples_per_partition = info->grouping;
-    const int possible_partitions = info->partitions;
-    const int partitions_per_word = info->phrase_dim;
-    const int n = info->end - info->begin;
-    const int partvals = n / samples_per_partition;
-    const vbm_book *phrasebook = &s->book[info->groupbook];
-    int i, j, k, st;
-
-    for (st = 0; st < info->stages; st++) {
-        for (i = 0; i < partvals;) {
-            if (st == 0) {
-                for (j = 0; j < nvec; j++) {
-                    long val = PW(j, i);
-                    for (k = 1; k < partitions_per_word; k++) {
-                        val *= possible_partitions;
-                        if (i + k < partvals) val += PW(j, i + k);
-                    }
-                    if (val < phrasebook->entries) book_encode(phrasebook, (int)val, w);
-                }
-            }
-
-            for (k = 0; k < partitions_per_word && i < partvals; k++, i++) {
-                long offset = (long)i * samples_per_partition + info->begin;
-                for (j = 0; j < nvec; j++) {
-                    int cls = PW(j, i);
-                    if (info->secondstages[cls] & (1 << st)) {
-                        int bi = info->partbook[cls][st];
-                        if (bi >= 0) {
-                            const vbm_book *book = &s->book[bi];
-                            const int dim = book->dim;
-                            const int step = samples_per_partition / dim;
-                            int *base = vec[j] + (size_t)offset * stride[j];
-                            for (int t = 0; t < step; t++) {
-                                int a[VBM_MAX_BOOK_DIM];
-                                int *vp = base + (size_t)t * dim * stride[j];
-                                for (int d = 0; d < dim; d++) a[d] = vp[(size_t)d * stride[j]];
-                                int entry = besterror(book, a);
-                                for (int d = 0; d < dim; d++) vp[(size_t)d * stride[j]] = a[d];
-                                book_encode(book, entry, w);
-                            }
-                        }
-                    }
-                }
-            }
+    res_view v;
+    v.r = &b.setup->residue[info->residuesubmap[sm]];
+    v.nb = 0;
+    v.used = 0;
+    int any = 0;
+    for (int j = 0; j < b.ch; j++)
+        if (info->chmuxlist[j] == sm) {
+            const int nz = b.nonzero[col0 + j] ? 1 : 0;
+            v.chlist[v.nb++] = j;
+            any |= nz;
+            if (nz && v.r->type != 2) v.vch[v.used++] = j;
         }
-    }
-#undef PW
+    if (v.r->type == 2) v.used = any ? 1 : 0;
+    v.spp = v.r->grouping;
+    v.partvals = (v.r->end - v.r->begin) / v.spp;
+    return v;
 }
 
-__global__ void k_pack(vbm_batch b)
+#define SBT(sb) ((size_t)((sb) >> 6) * b.sb_slab_words + ((sb) & 63))
+#define IWC(cc, x) b.iworkT[(size_t)((col0 + (cc)) >> 6) * b.slab_words + (size_t)(x) * 64 + ((col0 + (cc)) & 63)]
+#define PW(jv, iv) partword[((size_t)(jv) * v.partvals + (iv)) * 64]
+#define LEN(stg, jv, iv) lenT[(((size_t)(stg) * b.ch + (jv)) * v.partvals + (iv)) * 64]
+#define OFF(stg, jv, iv) offT[(((size_t)(stg) * b.ch + (jv)) * v.partvals + (iv)) * 64]
+
+__global__ void k_pack_head(vbm_batch b)
 {
     const int sb = blockIdx.x * blockDim.x + threadIdx.x;
     if (sb >= b.nsb) return;
-    const size_t SW = b.slab_words, SWS = b.sb_slab_words;
-    const size_t sbt = (size_t)(sb >> 6) * SWS + (sb & 63);   // this lane in the stream-block slab
+    const size_t SW = b.slab_words;
     const vbm_setup *s = b.setup;
     const vbm_map *info = &s->map[b.W];
     const int ch = b.ch;
-    const int n = b.n;
     const size_t col0 = (size_t)sb * ch;
     const int sid = b.stream_id[sb];
     int i, j, k;
 
+    // nonzero[] after coupling (lib/psy.c:5133-5140); couple/quantise left the flags untouched
+    for (i = 0; i < info->coupling_steps; i++) {
+        const size_t m = col0 + info->coupling_mag[i], a = col0 + info->coupling_ang[i];
+        if (b.nonzero[m] || b.nonzero[a]) {
+            b.nonzero[m] = 1;
+            b.nonzero[a] = 1;
+        }
+    }
+
     BitW w;
-    w.base = b.packetT + (size_t)(sb >> 6) * b.max_packet_bytes * 64 + (sb & 63);
-    w.stride = 64;
-    w.nbytes = 0;
-    w.maxbytes = b.max_packet_bytes;
+    w.base = (uint32_t *)b.packetT + (size_t)(sb >> 6) * (b.max_packet_bytes / 4) * 64 + (sb & 63);
+    w.nwords = 0;
+    w.maxwords = b.max_packet_bytes / 4;
     w.acc = 0;
     w.nbits = 0;
-    w.overflow = 0;
 
     // packet type, mode number, window flags (lib/mapping0.c:1211-1218)
     bw_write(w, 0, 1);
@@ -253,97 +257,7 @@ __global__ void k_pack(vbm_batch b)
         }
 #undef OUTV
     }
-
-    // ---- residue, submap by submap (lib/mapping0.c:1273-1295) -------------------------------
-    for (int sm = 0; sm < info->submaps; sm++) {
-        const vbm_residue *r = &s->residue[info->residuesubmap[sm]];
-        int chlist[VBM_MAXCH], zb[VBM_MAXCH];
-        int nb = 0;
-        for (j = 0; j < ch; j++)
-            if (info->chmuxlist[j] == sm) {
-                zb[nb] = b.nonzero[col0 + j] ? 1 : 0;
-                chlist[nb++] = j;
-            }
-        const int samples_per_partition = r->grouping;
-        const int possible_partitions = r->partitions;
-        const int rn = r->end - r->begin;
-        const int partvals = rn / samples_per_partition;
-        // partword rows: [vector j][partition i], all submaps share the buffer (used one at a time)
-        int *partword = b.partwordT + sbt;
-        const size_t pw_stride = 64;
-        const int pw_rows = partvals;
-#define PW(jv, iv) partword[((size_t)(jv) * pw_rows + (iv)) * pw_stride]
-#define IWC(cc, x) b.iworkT[(size_t)((col0 + (cc)) >> 6) * SW + (size_t)(x) * 64 + ((col0 + (cc)) & 63)]
-
-        if (r->type == 2) {
-            int used = 0;
-            for (j = 0; j < nb; j++)
-                if (zb[j]) used++;
-            if (!used) continue;
-            // _2class (lib/res0.c:473-526)
-            {
-                int l = r->begin / nb;
-                for (i = 0; i < partvals; i++) {
-                    int magmax = 0, angmax = 0;
-                    for (j = 0; j < samples_per_partition; j += nb) {
-                        int v0 = abs(IWC(chlist[0], l));
-                        if (v0 > magmax) magmax = v0;
-                        for (k = 1; k < nb; k++) {
-                            int vk = abs(IWC(chlist[k], l));
-                            if (vk > angmax) angmax = vk;
-                        }
-                        l++;
-                    }
-                    for (j = 0; j < possible_partitions - 1; j++)
-                        if (magmax <= r->classmetric1[j] && angmax <= r->classmetric2[j]) break;
-                    PW(0, i) = j;
-                }
-            }
-            // res2_forward: interleave into one vector (lib/res0.c:781-787), then _01forward
-            int *work = b.workvqT + sbt;
-            for (i = 0; i < nb; i++)
-                for (j = 0, k = i; j < n; j++, k += nb) work[(size_t)k * 64] = IWC(chlist[i], j);
-            int *vec[1] = {work};
-            size_t stride[1] = {64};
-            forward01(w, s, r, vec, stride, 1, partword, pw_stride, pw_rows);
-        } else {
-            // res1_class / res1_forward: only the nonzero channels take part (lib/res0.c:715-745)
-            int *vec[VBM_MAXCH];
-            size_t stride[VBM_MAXCH];
-            int used = 0;
-            for (j = 0; j < nb; j++)
-                if (zb[j]) {
-                    vec[used] = &IWC(chlist[j], 0);
-                    stride[used] = 64;
-                    used++;
-                }
-            if (!used) continue;
-            // _01class (lib/res0.c:406-468)
-            {
-                float scale = (float)(100. / samples_per_partition);
-                for (i = 0; i < partvals; i++) {
-                    int offset = i * samples_per_partition + r->begin;
-                    for (j = 0; j < used; j++) {
-                        int mx = 0, ent = 0;
-                        for (k = 0; k < samples_per_partition; k++) {
-                            int v = abs(vec[j][(size_t)(offset + k) * stride[j]]);
-                            if (v > mx) mx = v;
-                            ent += v;
-                        }
-                        ent = (int)((float)ent * scale);
-                        for (k = 0; k < possible_partitions - 1; k++)
-                            if (mx <= r->classmetric1[k] && (r->classmetric2[k] < 0 || ent < r->classmetric2[k])) break;
-                        PW(j, i) = k;
-                    }
-                }
-            }
-            forward01(w, s, r, vec, stride, used, partword, pw_stride, pw_rows);
-        }
-#undef PW
-#undef IWC
-    }
-
-    b.packet_bytes[sb] = w.overflow ? -1 : bw_finish(w);
+    b.packet_bits[sb] = bw_finish(w);
 
     // ---- aoTuV block-state update (lib/mapping0.c:1297-1305) --------------------------------
     {
@@ -362,10 +276,232 @@ __global__ void k_pack(vbm_batch b)
     }
 }
 
+__global__ void k_res_class(vbm_batch b, int sm, int nchunks)
+{
+    const int sb = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sb >= b.nsb) return;
+    const vbm_map *info = &b.setup->map[b.W];
+    const size_t col0 = (size_t)sb * b.ch;
+    const res_view v = residue_view(b, info, sm, col0);
+    if (!v.used) return;
+    const vbm_residue *r = v.r;
+    const int i0 = (int)((long)v.partvals * blockIdx.y / nchunks), i1 = (int)((long)v.partvals * (blockIdx.y + 1) / nchunks);
+    int *partword = b.partwordT + SBT(sb);
+    const int possible_partitions = r->partitions;
+    int i, j, k;
+
+    if (r->type == 2) {
+        // _2class (lib/res0.c:473-526) and the interleave of res2_forward (:781-787) for these partitions
+        int *work = b.workvqT + SBT(sb);
+        const int nb = v.nb;
+        const int lsteps = (v.spp + nb - 1) / nb;   // the source advances l once per nb samples of a partition
+        for (i = i0; i < i1; i++) {
+            int magmax = 0, angmax = 0;
+            int l = r->begin / nb + i * lsteps;
+            for (j = 0; j < v.spp; j += nb, l++) {
+                int v0 = abs(IWC(v.chlist[0], l));
+                if (v0 > magmax) magmax = v0;
+                for (k = 1; k < nb; k++) {
+                    int vk = abs(IWC(v.chlist[k], l));
+                    if (vk > angmax) angmax = vk;
+                }
+            }
+            for (j = 0; j < possible_partitions - 1; j++)
+                if (magmax <= r->classmetric1[j] && angmax <= r->classmetric2[j]) break;
+            PW(0, i) = j;
+        }
+        // interleaved vector work[x] = in[x % nb][x / nb] over these partitions' samples
+        for (int x = r->begin + i0 * v.spp; x < r->begin + i1 * v.spp; x++)
+            work[(size_t)x * 64] = IWC(v.chlist[x % nb], x / nb);
+    } else {
+        // _01class (lib/res0.c:406-468): only the nonzero channels take part (:715-745)
+        const float scale = (float)(100. / v.spp);
+        for (i = i0; i < i1; i++) {
+            const int offset = i * v.spp + r->begin;
+            for (j = 0; j < v.used; j++) {
+                int mx = 0, ent = 0;
+                for (k = 0; k < v.spp; k++) {
+                    int a = abs(IWC(v.vch[j], offset + k));
+                    if (a > mx) mx = a;
+                    ent += a;
+                }
+                ent = (int)((float)ent * scale);
+                for (k = 0; k < possible_partitions - 1; k++)
+                    if (mx <= r->classmetric1[k] && (r->classmetric2[k] < 0 || ent < r->classmetric2[k])) break;
+                PW(j, i) = k;
+            }
+        }
+    }
+}
+
+__global__ void k_res_vq(vbm_batch b, int sm, int nchunks)
+{
+    const int sb = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sb >= b.nsb) return;
+    const vbm_setup *s = b.setup;
+    const vbm_map *info = &s->map[b.W];
+    const size_t col0 = (size_t)sb * b.ch;
+    const res_view v = residue_view(b, info, sm, col0);
+    if (!v.used) return;
+    const vbm_residue *r = v.r;
+    const int i0 = (int)((long)v.partvals * blockIdx.y / nchunks), i1 = (int)((long)v.partvals * (blockIdx.y + 1) / nchunks);
+    const int *partword = b.partwordT + SBT(sb);
+    int *lenT = b.vqlenT + SBT(sb);
+    uint64_t *slot = b.vqcodeT + (size_t)(sb >> 6) * b.vq_slab_words + (sb & 63);
+    int *work = b.workvqT + SBT(sb);
+    const int veclen = (r->type == 2) ? b.n * v.nb : b.n;
+    const size_t stage_slots = (size_t)b.n * b.ch;
+
+    for (int i = i0; i < i1; i++) {
+        const int offset = i * v.spp + r->begin;
+        for (int j = 0; j < v.used; j++) {
+            const int cls = PW(j, i);
+            for (int st = 0; st < r->stages; st++) {
+                int bits = 0;
+                const int bi = (r->secondstages[cls] & (1 << st)) ? r->partbook[cls][st] : -1;
+                if (bi >= 0) {
+                    const vbm_book *book = &s->book[bi];
+                    const int dim = book->dim;
+                    const int step = v.spp / dim;
+                    uint64_t *sl = slot + (st * stage_slots + (size_t)j * veclen + offset) * 64;
+                    for (int t = 0; t < step; t++) {
+                        int a[VBM_MAX_BOOK_DIM];
+                        const int x0 = offset + t * dim;
+                        if (r->type == 2) {
+                            for (int d = 0; d < dim; d++) a[d] = work[(size_t)(x0 + d) * 64];
+                        } else {
+                            for (int d = 0; d < dim; d++) a[d] = IWC(v.vch[j], x0 + d);
+                        }
+                        const int entry = besterror(book, a);
+                        if (r->type == 2) {
+                            for (int d = 0; d < dim; d++) work[(size_t)(x0 + d) * 64] = a[d];
+                        } else {
+                            for (int d = 0; d < dim; d++) IWC(v.vch[j], x0 + d) = a[d];
+                        }
+                        uint64_t cw = 0;
+                        if (entry >= 0 && entry < book->entries) {
+                            const int len = book->lengthlist[entry];
+                            cw = (uint64_t)book->codelist[entry] | ((uint64_t)(uint32_t)len << 32);
+                            bits += len;
+                        }
+                        sl[(size_t)t * 64] = cw;
+                    }
+                }
+                LEN(st, j, i) = bits;
+            }
+        }
+    }
+}
+
+__global__ void k_res_offsets(vbm_batch b, int sm)
+{
+    const int sb = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sb >= b.nsb) return;
+    const vbm_setup *s = b.setup;
+    const vbm_map *info = &s->map[b.W];
+    const size_t col0 = (size_t)sb * b.ch;
+    const res_view v = residue_view(b, info, sm, col0);
+    const int maxwords = b.max_packet_bytes / 4;
+    int pos = b.packet_bits[sb];
+    if (v.used) {
+        const vbm_residue *r = v.r;
+        const int *partword = b.partwordT + SBT(sb);
+        const int *lenT = b.vqlenT + SBT(sb);
+        int *offT = b.vqoffT + SBT(sb);
+        uint32_t *words = (uint32_t *)b.packetT + (size_t)(sb >> 6) * maxwords * 64 + (sb & 63);
+        const vbm_book *phrasebook = &s->book[r->groupbook];
+        const int partitions_per_word = r->phrase_dim;
+        // emission order of _01forward, lib/res0.c:574-636
+        for (int st = 0; st < r->stages; st++) {
+            for (int i = 0; i < v.partvals;) {
+                if (st == 0) {
+                    for (int j = 0; j < v.used; j++) {
+                        long val = PW(j, i);
+                        for (int k = 1; k < partitions_per_word; k++) {
+                            val *= r->partitions;
+                            if (i + k < v.partvals) val += PW(j, i + k);
+                        }
+                        if (val < phrasebook->entries) {
+                            const int len = phrasebook->lengthlist[val];
+                            or_bits(words, maxwords, pos, phrasebook->codelist[val], len);
+                            pos += len;
+                        }
+                    }
+                }
+                for (int k = 0; k < partitions_per_word && i < v.partvals; k++, i++)
+                    for (int j = 0; j < v.used; j++) {
+                        OFF(st, j, i) = pos;
+                        pos += LEN(st, j, i);
+                    }
+            }
+        }
+        b.packet_bits[sb] = pos;
+    }
+    b.packet_bytes[sb] = (pos > maxwords * 32) ? -1 : (pos + 7) / 8;
+}
+
+__global__ void k_res_emit(vbm_batch b, int sm, int nchunks)
+{
+    const int sb = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sb >= b.nsb) return;
+    const vbm_map *info = &b.setup->map[b.W];
+    const size_t col0 = (size_t)sb * b.ch;
+    const res_view v = residue_view(b, info, sm, col0);
+    if (!v.used) return;
+    const vbm_residue *r = v.r;
+    const int i0 = (int)((long)v.partvals * blockIdx.y / nchunks), i1 = (int)((long)v.partvals * (blockIdx.y + 1) / nchunks);
+    const int *lenT = b.vqlenT + SBT(sb);
+    const int *offT = b.vqoffT + SBT(sb);
+    const uint64_t *slot = b.vqcodeT + (size_t)(sb >> 6) * b.vq_slab_words + (sb & 63);
+    const int maxwords = b.max_packet_bytes / 4;
+    uint32_t *words = (uint32_t *)b.packetT + (size_t)(sb >> 6) * maxwords * 64 + (sb & 63);
+    const int veclen = (r->type == 2) ? b.n * v.nb : b.n;
+    const size_t stage_slots = (size_t)b.n * b.ch;
+
+    for (int st = 0; st < r->stages; st++)
+        for (int i = i0; i < i1; i++) {
+            const int offset = i * v.spp + r->begin;
+            for (int j = 0; j < v.used; j++) {
+                int remaining = LEN(st, j, i);
+                if (remaining <= 0) continue;
+                const int pos = OFF(st, j, i);
+                const uint64_t *sl = slot + (st * stage_slots + (size_t)j * veclen + offset) * 64;
+                int wi = pos >> 5;
+                int nbits = pos & 31;   // bits below the run's start stay zero in acc
+                uint64_t acc = 0;
+                for (int t = 0; t < v.spp && remaining > 0; t++) {
+                    const uint64_t cw = sl[(size_t)t * 64];
+                    const int len = (int)(cw >> 32);
+                    if (!len) continue;
+                    acc |= (uint64_t)(uint32_t)cw << nbits;
+                    nbits += len;
+                    remaining -= len;
+                    if (nbits >= 32) {
+                        if (wi < maxwords) atomicOr(&words[(size_t)wi * 64], (uint32_t)acc);
+                        acc >>= 32;
+                        nbits -= 32;
+                        wi++;
+                    }
+                }
+                if (nbits > 0 && wi < maxwords) atomicOr(&words[(size_t)wi * 64], (uint32_t)acc);
+            }
+        }
+}
+
 }  // namespace
 
 extern "C" int vbm_launch_pack(const vbm_batch *b, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_pack, dim3((unsigned)((b->nsb + 63) / 64)), dim3(64), 0, st, *b);
+    const unsigned tiles = (unsigned)((b->nsb + 63) / 64);
+    if (hipMemsetAsync(b->packetT, 0, (size_t)tiles * 64 * b->max_packet_bytes, st) != hipSuccess) return -2;
+    hipLaunchKernelGGL(k_pack_head, dim3(tiles), dim3(64), 0, st, *b);
+    for (int sm = 0; sm < b->pack_submaps; sm++) {
+        int nchunks = b->pack_partvals[sm] < 16 ? b->pack_partvals[sm] : 16;
+        if (nchunks < 1) nchunks = 1;
+        hipLaunchKernelGGL(k_res_class, dim3(tiles, (unsigned)nchunks), dim3(64), 0, st, *b, sm, nchunks);
+        hipLaunchKernelGGL(k_res_vq, dim3(tiles, (unsigned)nchunks), dim3(64), 0, st, *b, sm, nchunks);
+        hipLaunchKernelGGL(k_res_offsets, dim3(tiles), dim3(64), 0, st, *b, sm);
+        hipLaunchKernelGGL(k_res_emit, dim3(tiles, (unsigned)nchunks), dim3(64), 0, st, *b, sm, nchunks);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

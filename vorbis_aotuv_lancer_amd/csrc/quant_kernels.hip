@@ -4,9 +4,17 @@
 //                       flag_lossless :4584-4624, noise_normalize :4732-4854 (ssort :4709),
 //                       lossless_coupling(f) :4626-4658, min_indemnity_dipole_hypot :4660-4673,
 //                       VBR blob PACKETBLOBS/2.
-// Partitions are walked in order inside the lane because aoTuV M6 carries `side_resdef` from
-// one partition to the next (:5032-5034) and `residue_def` is an order-bound float sum; the
-// per-partition scratch (raw/quant/floor/res/flag, <= 8 ch x 32 bins) lives in private memory.
+// A partition only depends on its predecessor through aoTuV M6's `side_resdef` (:5032-5034): the
+// previous partition's mean magnitude/angle residue difference of the coupled pair.  When the
+// coupling steps of the mapping use disjoint channels (stereo: one step) that number depends
+// on nothing but the previous partition's mdct / floor values, so
+//   k_couple_m6stats   computes it for every partition in the M6 range (one partition per
+//                      blockIdx.y) into m6defT, and
+//   k_couple_quantize  then runs the partitions sliced over blockIdx.y, reading side_resdef from
+//                      the table.
+// Mappings whose steps share channels keep the carried value and run as one slice.
+// `residue_def` is an order-bound float sum inside a partition; the per-partition scratch
+// (raw/quant/floor/res/flag, ch x 32 bins) lives in private memory.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "batch.h"
@@ -211,7 +219,58 @@ __device__ __forceinline__ float noise_normalize(const vbm_psy *p, const int lim
 #undef OUT
 }
 
-__global__ void k_couple_quantize(vbm_batch b)
+// M6 statistics of one partition, lib/psy.c:5010-5034 (the part that does not depend on side_resdef)
+__global__ void k_couple_m6stats(vbm_batch b)
+{
+    const int sb = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sb >= b.nsb) return;
+    const size_t SW = b.slab_words;
+    const vbm_setup *s = b.setup;
+    const vbm_psy *p = &s->psy[b.block_mode];
+    const vbm_map *vi = &s->map[b.W];
+    const int n = p->n;
+    const int partition = (p->normal_p ? p->normal_partition : 16);
+    const int pi = blockIdx.y, i = pi * partition;
+    const int jn = partition > n - i ? n - i : partition;
+    const size_t col0 = (size_t)sb * b.ch;
+    float *m6 = b.m6defT + (size_t)(sb >> 6) * b.sb_slab_words + (sb & 63);
+#define CT(buf, k, x) (buf)[(size_t)((col0 + (k)) >> 6) * SW + (size_t)(x) * 64 + ((col0 + (k)) & 63)]
+    for (int step = 0; step < vi->coupling_steps; step++) {
+        const int Mi = vi->coupling_mag[step], Ai = vi->coupling_ang[step];
+        const int nzM = b.nonzero[col0 + Mi], nzA = b.nonzero[col0 + Ai];
+        float def = -1.f;
+        if (nzM || nzA) {
+            int rp = 0, pp = 0;
+            float residue_def = 0;
+            for (int j = 0; j < jn; j++) {
+                float resM = 0.f, resA = 0.f, reM = 0.f, reA = 0.f;
+                if (nzM) {
+                    const float m = CT(b.mdctT, Mi, i + j);
+                    resM = m / s->fromdB[CT(b.iworkT, Mi, i + j)];
+                    reM = m * m;
+                    if (m < 0.f) reM *= -1.f;
+                }
+                if (nzA) {
+                    const float m = CT(b.mdctT, Ai, i + j);
+                    resA = m / s->fromdB[CT(b.iworkT, Ai, i + j)];
+                    reA = m * m;
+                    if (m < 0.f) reA *= -1.f;
+                }
+                if (existe(resM, 0.5) || existe(resA, 0.5)) {
+                    if (refer_phase(reM, reA)) rp++;
+                    else pp++;
+                    residue_def = (float)((double)residue_def + fabs((double)fabsf(resM) - (double)fabsf(resA)));
+                }
+            }
+            const int ap = rp + pp;
+            if (ap != 0) def = residue_def / ap;
+        }
+        m6[((size_t)pi * vi->coupling_steps + step) * 64] = def;
+    }
+#undef CT
+}
+
+__global__ void k_couple_quantize(vbm_batch b, int nchunks)
 {
     const int sb = blockIdx.x * blockDim.x + threadIdx.x;
     if (sb >= b.nsb) return;
@@ -264,7 +323,11 @@ __global__ void k_couple_quantize(vbm_batch b)
     if (vi->coupling_steps == 1) prae = (float)0.34;
     else prae = (float)0.825;
 
-    for (i = 0, pi = 0; i < lowpassr; i += partition, pi++) {
+    const int nparts = (lowpassr + partition - 1) / partition;
+    const int pi0 = (int)((long)nparts * blockIdx.y / nchunks), pi1 = (int)((long)nparts * (blockIdx.y + 1) / nchunks);
+    const float *m6 = b.m6defT + (size_t)(sb >> 6) * b.sb_slab_words + (sb & 63);
+
+    for (pi = pi0, i = pi0 * partition; pi < pi1; i += partition, pi++) {
         int k, j, jn = partition > n - i ? n - i : partition;
         int step, track = 0;
 
@@ -337,8 +400,11 @@ __global__ void k_couple_quantize(vbm_batch b)
 
                     if (ap != 0) {
                         float temp_def = residue_def = residue_def / ap;
-                        if (side_resdef[step] > 0)
-                            residue_def = (float)((double)temp_def * 0.5 + (double)side_resdef[step] * 0.5);
+                        float side = side_resdef[step];
+                        if (b.couple_parallel)
+                            side = (pi > 0) ? m6[((size_t)(pi - 1) * vi->coupling_steps + step) * 64] : -1.f;
+                        if (side > 0)
+                            residue_def = (float)((double)temp_def * 0.5 + (double)side * 0.5);
                         side_resdef[step] = temp_def;
                         if (residue_def > 1.f) {
                             for (j = 0; j < jn; j++)
@@ -401,18 +467,14 @@ __global__ void k_couple_quantize(vbm_batch b)
         }
     }
 
+    // bins past the lowpass (sliced like the partitions); the nonzero[] propagation over the coupling
+    // steps (lib/psy.c:5133-5140) is applied by k_pack_head, after every slice has read the flags
     if (lowpassr < n) {
+        const int z0 = lowpassr + (int)((long)(n - lowpassr) * blockIdx.y / nchunks);
+        const int z1 = lowpassr + (int)((long)(n - lowpassr) * (blockIdx.y + 1) / nchunks);
         for (int k = 0; k < ch; k++)
-            for (int j = lowpassr; j < n; j++) IW(k, j) = 0;
+            for (int j = z0; j < z1; j++) IW(k, j) = 0;
     }
-
-    for (i = 0; i < vi->coupling_steps; i++) {
-        if (nonzero[vi->coupling_mag[i]] || nonzero[vi->coupling_ang[i]]) {
-            nonzero[vi->coupling_mag[i]] = 1;
-            nonzero[vi->coupling_ang[i]] = 1;
-        }
-    }
-    for (i = 0; i < ch; i++) b.nonzero[col0 + i] = nonzero[i];
 #undef MD
 #undef CT
 #undef EP
@@ -424,6 +486,13 @@ __global__ void k_couple_quantize(vbm_batch b)
 
 extern "C" int vbm_launch_couple_quantize(const vbm_batch *b, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_couple_quantize, dim3((unsigned)((b->nsb + 63) / 64)), dim3(64), 0, st, *b);
+    const unsigned tiles = (unsigned)((b->nsb + 63) / 64);
+    int nchunks = 1;
+    if (b->couple_parallel) {
+        if (b->couple_m6parts > 0)
+            hipLaunchKernelGGL(k_couple_m6stats, dim3(tiles, (unsigned)b->couple_m6parts), dim3(64), 0, st, *b);
+        nchunks = b->couple_parts < 16 ? (b->couple_parts > 0 ? b->couple_parts : 1) : 16;
+    }
+    hipLaunchKernelGGL(k_couple_quantize, dim3(tiles, (unsigned)nchunks), dim3(64), 0, st, *b, nchunks);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
