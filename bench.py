@@ -36,6 +36,7 @@ RATE = 44100
 QUALITY = 0.5
 N_LONG = 2048
 HOP = N_LONG // 2
+SPLIT = int(os.environ.get("VBM_BENCH_SPLIT", "1"))   # sub-batches per step, one HIP stream each
 DISTINCT_STEPS = 8              # PCM for this many consecutive blocks per stream is kept in HBM
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -116,14 +117,26 @@ def main():
     import vorbis_aotuv_lancer_amd as v
 
     setup = v.Setup(CHANNELS, RATE, QUALITY)
-    enc = v.Encoder(setup, STREAMS_PER_GPU)
     blocks = synth_blocks(dev, seed=1234 + rank)      # resident in HBM before timing starts
-    ids = np.arange(STREAMS_PER_GPU, dtype=np.int32)
-    wflags = np.full(STREAMS_PER_GPU, 3, dtype=np.uint8)   # lW = nW = long
     LONG = 3
+    # The 16384 streams of a step are submitted as SPLIT sub-batches, each to its own encoder object
+    # (its share of the stream state + workspace) on its own HIP stream, so the serial stages of one
+    # sub-batch (few wavefronts) overlap with the wide stages of another.
+    per = STREAMS_PER_GPU // SPLIT
+    assert per * SPLIT == STREAMS_PER_GPU
+    encs = [v.Encoder(setup, per) for _ in range(SPLIT)]
+    enc = encs[0]
+    queues = [torch.cuda.Stream(device=dev) for _ in range(SPLIT)] if SPLIT > 1 else [torch.cuda.current_stream()]
+    ids = np.arange(per, dtype=np.int32)
+    wflags = np.full(per, 3, dtype=np.uint8)   # lW = nW = long
+    parts = [[blk[p * per:(p + 1) * per] for blk in blocks] for p in range(SPLIT)]   # contiguous views
 
     def step(k):
-        return enc.analysis_batch(LONG, ids, wflags, blocks[k % DISTINCT_STEPS])
+        out = None
+        for p in range(SPLIT):
+            with torch.cuda.stream(queues[p]):
+                out = encs[p].analysis_batch(LONG, ids, wflags, parts[p][k % DISTINCT_STEPS])
+        return out
 
     def barrier():
         if dist is not None:
@@ -133,13 +146,16 @@ def main():
     for k in range(args.warmup):
         step(k)
     barrier()
-    enc.profile_begin(args.steps)      # HIP events between the stage kernels, on the launch stream
+    for each in encs:
+        each.profile_begin(args.steps)  # HIP events between the stage kernels, on the stream each is launched on
     t0 = time.perf_counter()
     for k in range(args.steps):
         pk, nb = step(args.warmup + k)
     barrier()
     dt = time.perf_counter() - t0
     stage_ms, calls = enc.profile_end()
+    for other in encs[1:]:
+        other.profile_end()
     if dist is not None:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -148,21 +164,29 @@ def main():
     audio_s_per_step = STREAMS_PER_GPU * HOP / RATE * world
     value = audio_s_per_step * args.steps / dt
     ncb = STREAMS_PER_GPU * CHANNELS
-    per_launch_ms = {k: ms / max(calls, 1) for k, ms in stage_ms.items()}
-    dominant = max(per_launch_ms, key=per_launch_ms.get)
+    # the three transform stages are launched once per call on the whole batch, the later stages once
+    # per sub-batch (include/vorbis_mi355x.h, vbm_encoder_set_sub_batches)
+    sub = enc.sub_batches
+    front = ("window_mdct", "window_fft_log", "transpose")
+    launches = {k: max(calls, 1) * SPLIT * (1 if k in front else sub) for k in stage_ms}
+    units = {k: (ncb // SPLIT) // (1 if k in front else sub) for k in stage_ms}   # channel-blocks per launch
+    per_launch_ms = {k: ms / launches[k] for k, ms in stage_ms.items()}
+    per_step_ms = {k: ms / max(calls, 1) for k, ms in stage_ms.items()}       # summed over the launches of a step
+    dominant = max(per_step_ms, key=per_step_ms.get)
 
     def roof(stage):
         ms = per_launch_ms[stage]
-        ach = STAGE_BYTES[stage] * ncb / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        ach = STAGE_BYTES[stage] * units[stage] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         return {"kernel": stage, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBPS, "traffic": None,
-                "algorithmic_bytes_per_launch": STAGE_BYTES[stage] * ncb, "kernel_ms": ms}
+                "algorithmic_bytes_per_launch": STAGE_BYTES[stage] * units[stage],
+                "channel_blocks_per_launch": units[stage], "kernel_ms": ms}
 
     traffic = {}
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
-        if tj.get("channel_blocks_per_launch") == ncb:
+        if tj.get("channel_blocks_per_step") == ncb and tj.get("sub_batches") == sub:
             traffic = tj.get("hbm_bytes_per_launch", {})
 
     if rank == 0:
@@ -191,11 +215,14 @@ def main():
                 "block_switching": "not in the timed region (long blocks only; envelope search / carve-out is "
                                    "SURVEY.md §8f N1)",
                 "mean_packet_bytes": mean_bytes,
-                "parallelism": f"stream-shard x{world} (no collective)",
+                "parallelism": f"stream-shard x{world} (no collective); {SPLIT} sub-batch(es) of {per} streams per "
+                               "step on separate HIP streams",
             },
             "roofline": r_dom,
             "mdct_roofline": r_mdct,
             "stage_ms_per_launch": per_launch_ms,
+            "stage_ms_per_step": per_step_ms,
+            "sub_batches": sub,
         }
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()

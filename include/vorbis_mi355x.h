@@ -142,10 +142,20 @@ int vbm_analysis_batch(vbm_encoder *enc, int block_mode, int nsb, const int *str
  * "poste" "packet_bytes".  d_out may be NULL to query rows/kind ('f' float32, 'i' int32). */
 int vbm_encoder_fetch(vbm_encoder *enc, const char *name, void *d_out, long *rows, char *kind, void *stream);
 
-/* Per-stage timing of vbm_analysis_batch: HIP events are recorded on the launch stream between
- * the pipeline's kernels for the next `max_calls` calls; profile_end waits for the last one and
- * returns the summed milliseconds per stage (vbm_encoder_stage_count() entries, names from
- * vbm_encoder_stage_name) and the number of calls covered. */
+/* Sub-batches.  The transforms run on the whole batch; the stages after them run as `n` slices of
+ * the batch (multiples of 64 stream-blocks), each on an internal HIP stream forked from and joined
+ * back to the caller's stream with events, so that the serial few-wavefront kernels of one slice
+ * overlap with the wide kernels of the others.  Results do not depend on n.  Default 1
+ * (environment VBM_SUB_BATCHES overrides at create); n = 1 launches everything on the caller's
+ * stream. */
+int vbm_encoder_set_sub_batches(vbm_encoder *enc, int n);
+int vbm_encoder_sub_batches(const vbm_encoder *enc);
+
+/* Per-stage timing of vbm_analysis_batch: HIP events are recorded between the pipeline's kernels,
+ * on the stream each kernel is launched on, for the next `max_calls` calls; profile_end waits for
+ * the device and returns the summed milliseconds per stage over all launches
+ * (vbm_encoder_stage_count() entries, names from vbm_encoder_stage_name) and the number of calls
+ * covered.  The first three stages are launched once per call, the others once per sub-batch. */
 int vbm_encoder_profile_begin(vbm_encoder *enc, int max_calls);
 int vbm_encoder_profile_end(vbm_encoder *enc, float *stage_ms, int *ncalls);
 int vbm_encoder_stage_count(void);

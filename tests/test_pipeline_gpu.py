@@ -28,13 +28,15 @@ def oracle_blocks(oracle, ch, rate, q, seconds, seed):
     return out
 
 
-def run_case(oracle, cuda, ch, rate, q, nstreams, seconds, check_stages=True, res1_channels=()):
+def run_case(oracle, cuda, ch, rate, q, nstreams, seconds, check_stages=True, res1_channels=(), sub_batches=1):
     import vorbis_aotuv_lancer_amd as v
     streams = [oracle_blocks(oracle, ch, rate, q, seconds, seed=100 + s) for s in range(nstreams)]
     nsteps = min(len(b) for b in streams)
     assert nsteps > 20
     setup = v.Setup(ch, rate, q)
     enc = v.Encoder(setup, nstreams)
+    enc.set_sub_batches(sub_batches)
+    assert enc.sub_batches == sub_batches
     seen_modes = set()
     mismatches = []
     for k in range(nsteps):
@@ -96,3 +98,9 @@ def test_stereo_q1_packet_parity(oracle, cuda):
 def test_surround_51_q8_packet_parity(oracle, cuda):
     # 6 channels, two submaps: 5-channel res-2 (uncoupled) + LFE res-1
     run_case(oracle, cuda, 6, 48000, 0.8, nstreams=6, seconds=3.0, res1_channels=(5,))
+
+
+def test_stereo_q5_many_streams_in_sub_batches(oracle, cuda):
+    """150 streams = 3 tiles of 64 stream-blocks, encoded as 2 slices on separate internal HIP streams
+    (vbm_encoder_set_sub_batches): packets must still equal the oracle's for every stream."""
+    run_case(oracle, cuda, 2, 44100, 0.5, nstreams=150, seconds=0.7, check_stages=False, sub_batches=2)

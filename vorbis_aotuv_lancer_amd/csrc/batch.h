@@ -41,6 +41,7 @@ struct vbm_batch {
     const float *pcm;               // [ncb][N] un-windowed block PCM
     float *mdct_bm;                 // [ncb][n]
     float *logfft_bm;               // [ncb][n]
+    uint16_t *qf_bm;                // [ncb][n]  floor fit input: dBquant(logmask) | (logmdct+twofitatten >= logmask) << 15
     float *local_ampmax;            // [ncb]
     uint8_t *wflags_cb;             // [ncb] wflags replicated per channel-block
     // Tiled bin-major stage buffers.  Lanes are grouped in tiles of 64 (one wavefront); each tile
@@ -58,6 +59,7 @@ struct vbm_batch {
     float *seedT;                   // [total_octave_lines][L]
     float *ampstackT;               // [total_octave_lines][L]
     int *posstackT;                 // [total_octave_lines][L]
+    float *ntfixT;                  // [2][256][L]  temp / inmod of aoTuV M7 (noise branch; the seed arrays belong to the tone branch)
     float *poste;                   // [L]
     float *global_ampmax;           // [Ls]
     int *postT;                     // [VIF_POSIT+2][L]  floor posts (fit, then quantised by encode)

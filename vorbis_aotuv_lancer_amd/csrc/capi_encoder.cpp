@@ -7,6 +7,7 @@
 // block type, one per stream.  Kernel order = mapping0_forward (lib/mapping0.c:738-1322).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -34,16 +35,39 @@ struct vbm_encoder {
     uint8_t *d_wflags;
     // last batch (for vbm_encoder_fetch)
     int last_nsb, last_mode;
-    // optional per-stage timing (HIP events on the launch stream)
+    // sub-batches: the stages after the transforms run as `nsplit` tile-aligned slices of the batch,
+    // each on its own internal HIP stream (forked from / joined to the caller's stream by events), so
+    // the few-wavefront serial kernels of one slice overlap with the wide kernels of the others
+    int nsplit = 1;
+    std::vector<hipStream_t> sub;
+    hipEvent_t ev_fork = nullptr;
+    std::vector<hipEvent_t> ev_join;
+    // pinned staging of stream_ids / wflags (double-buffered; skipped when unchanged)
+    int *h_ids[2] = {nullptr, nullptr};
+    uint8_t *h_flags[2] = {nullptr, nullptr};
+    hipEvent_t ev_stage[2] = {nullptr, nullptr};
+    int stage_turn = 0;
+    std::vector<int> last_ids;
+    std::vector<uint8_t> last_flags;
+    // optional per-stage timing (HIP events on the stream each kernel is launched on)
     bool profiling = false;
-    std::vector<hipEvent_t> events;   // (NSTAGES+1) per recorded call
+    std::vector<hipEvent_t> events;   // pool; a (begin, end) pair per recorded stage launch
     size_t events_used = 0;
+    struct span { int stage; size_t begin, end; };
+    std::vector<span> spans;
+    int prof_calls = 0, prof_max_calls = 0;
+    // the tone-mask branch of a slice runs on its own stream beside the noise-mask branch
+    bool overlap_branches = true;
+    std::vector<hipStream_t> aux;
+    std::vector<hipEvent_t> ev_aux_fork, ev_aux_join;
 };
 
 static const char *const kStageNames[] = {"window_mdct", "window_fft_log", "transpose", "prologue", "noisemask",
                                           "tonemask", "offset_and_mix", "floor_fit", "floor_encode",
                                           "couple_quantize", "pack", "packet_out"};
 static const int kNumStages = (int)(sizeof(kStageNames) / sizeof(kStageNames[0]));
+static const int kFront = 3;                       // stages launched on the whole batch (caller's stream)
+static const int kBack = kNumStages - kFront;      // stages launched per slice
 
 static int round64(int x) { return (x + 63) & ~63; }
 
@@ -65,6 +89,17 @@ extern "C" void vbm_encoder_destroy(vbm_encoder *e)
     if (!e) return;
     for (void *p : e->allocs) (void)hipFree(p);
     for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : e->ev_join) (void)hipEventDestroy(ev);
+    for (hipStream_t q : e->sub) (void)hipStreamDestroy(q);
+    for (hipStream_t q : e->aux) (void)hipStreamDestroy(q);
+    for (hipEvent_t ev : e->ev_aux_fork) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : e->ev_aux_join) (void)hipEventDestroy(ev);
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    for (int i = 0; i < 2; i++) {
+        if (e->h_ids[i]) (void)hipHostFree(e->h_ids[i]);
+        if (e->h_flags[i]) (void)hipHostFree(e->h_flags[i]);
+        if (e->ev_stage[i]) (void)hipEventDestroy(e->ev_stage[i]);
+    }
     delete e;
 }
 
@@ -132,6 +167,7 @@ extern "C" int vbm_encoder_create(vbm_encoder **out, vbm_setup_handle *setup, in
     A(e->d_wflags, uint8_t, Ls);
     A(b.mdct_bm, float, L * nmax);
     A(b.logfft_bm, float, L * nmax);
+    A(b.qf_bm, uint16_t, L * nmax);
     A(b.local_ampmax, float, L);
     A(b.wflags_cb, uint8_t, L);
     // tiled slabs (batch.h): every per-bin array of a 64-lane tile sits in one contiguous slab
@@ -142,7 +178,7 @@ extern "C" int vbm_encoder_create(vbm_encoder **out, vbm_setup_handle *setup, in
                      o_tone = take(nmax), o_logmask = take(nmax), o_epeak = take(nmax), o_work = take(nmax),
                      o_npeak = take(nmax / 8 + 1), o_sum = take((size_t)5 * nmax), o_seed = take(e->max_oct),
                      o_amp = take(e->max_oct), o_pos = take(e->max_oct), o_post = take(VBM_VIF_POSIT + 2),
-                     o_fout = take(VBM_VIF_POSIT + 2), o_iwork = take(nmax);
+                     o_fout = take(VBM_VIF_POSIT + 2), o_iwork = take(nmax), o_ntfix = take(512);
         b.slab_words = rows * 64;
         float *slab;
         A(slab, float, (L / 64) * b.slab_words);
@@ -151,6 +187,7 @@ extern "C" int vbm_encoder_create(vbm_encoder **out, vbm_setup_handle *setup, in
         b.epeakT = slab + o_epeak; b.workT = slab + o_work; b.npeakT = slab + o_npeak; b.sumT = slab + o_sum;
         b.seedT = slab + o_seed; b.ampstackT = slab + o_amp; b.posstackT = (int *)(slab + o_pos);
         b.postT = (int *)(slab + o_post); b.floor_outT = (int *)(slab + o_fout); b.iworkT = (int *)(slab + o_iwork);
+        b.ntfixT = slab + o_ntfix;
 
         size_t srows = 0;
         auto stake = [&](size_t r) { size_t at = srows; srows += r; return at * 64; };
@@ -185,9 +222,60 @@ extern "C" int vbm_encoder_create(vbm_encoder **out, vbm_setup_handle *setup, in
 #undef A
     b.stream_id = e->d_stream_id;
     b.wflags = e->d_wflags;
+    for (int i = 0; i < 2; i++) {
+        if (hipHostMalloc((void **)&e->h_ids[i], Ls * sizeof(int), hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc((void **)&e->h_flags[i], Ls, hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&e->ev_stage[i], hipEventDisableTiming) != hipSuccess) {
+            vbm_encoder_destroy(e);
+            g_vbm_err = "hipHostMalloc / hipEventCreate (staging) failed";
+            return VBM_EHIP;
+        }
+    }
+    if (hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess) {
+        vbm_encoder_destroy(e);
+        return VBM_EHIP;
+    }
+    {
+        const char *env = getenv("VBM_SUB_BATCHES");
+        int rc2 = vbm_encoder_set_sub_batches(e, env ? atoi(env) : 1);
+        if (rc2) { vbm_encoder_destroy(e); return rc2; }
+        env = getenv("VBM_OVERLAP_BRANCHES");
+        if (env) e->overlap_branches = atoi(env) != 0;
+    }
     *out = e;
     return VBM_OK;
 }
+
+extern "C" int vbm_encoder_set_sub_batches(vbm_encoder *e, int n)
+{
+    if (!e || n < 1 || n > 64) return VBM_EINVAL;
+    while ((int)e->sub.size() < n) {
+        hipStream_t q;
+        hipEvent_t ev;
+        hipError_t err = hipStreamCreateWithFlags(&q, hipStreamNonBlocking);
+        if (err != hipSuccess) return vbm_set_hip_error(err, "hipStreamCreateWithFlags");
+        e->sub.push_back(q);
+        err = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (err != hipSuccess) return vbm_set_hip_error(err, "hipEventCreateWithFlags");
+        e->ev_join.push_back(ev);
+    }
+    while ((int)e->aux.size() < n) {
+        hipStream_t q;
+        hipEvent_t e1, e2;
+        hipError_t err = hipStreamCreateWithFlags(&q, hipStreamNonBlocking);
+        if (err != hipSuccess) return vbm_set_hip_error(err, "hipStreamCreateWithFlags");
+        e->aux.push_back(q);
+        if ((err = hipEventCreateWithFlags(&e1, hipEventDisableTiming)) != hipSuccess ||
+            (err = hipEventCreateWithFlags(&e2, hipEventDisableTiming)) != hipSuccess)
+            return vbm_set_hip_error(err, "hipEventCreateWithFlags");
+        e->ev_aux_fork.push_back(e1);
+        e->ev_aux_join.push_back(e2);
+    }
+    e->nsplit = n;
+    return VBM_OK;
+}
+
+extern "C" int vbm_encoder_sub_batches(const vbm_encoder *e) { return e ? e->nsplit : VBM_EINVAL; }
 
 extern "C" int vbm_encoder_max_packet_bytes(const vbm_encoder *e) { return e ? e->max_packet_bytes : VBM_EINVAL; }
 
@@ -246,6 +334,31 @@ static void configure(vbm_encoder *e, vbm_batch &b, int block_mode, int nsb, con
     }
 }
 
+// slice [sb0, sb0+nsb) of a configured batch; sb0 is a multiple of 64, so every tiled array starts on
+// a tile boundary (channel-block tiles as well: 64*ch channel-blocks)
+static vbm_batch slice_of(const vbm_batch &f, int sb0, int nsb, uint8_t *d_packets_unused = nullptr)
+{
+    (void)d_packets_unused;
+    vbm_batch v = f;
+    const size_t cb0 = (size_t)sb0 * f.ch;
+    const size_t ct = cb0 >> 6, stl = (size_t)sb0 >> 6;
+    v.nsb = nsb;
+    v.ncb = nsb * f.ch;
+    v.stream_id += sb0; v.wflags += sb0;
+    v.pcm += cb0 * f.N; v.mdct_bm += cb0 * f.n; v.logfft_bm += cb0 * f.n; v.qf_bm += cb0 * f.n;
+    v.local_ampmax += cb0; v.wflags_cb += cb0; v.poste += cb0; v.post_valid += cb0; v.nonzero += cb0;
+    v.global_ampmax += sb0; v.packet_bytes += sb0; v.packet_bits += sb0;
+    const size_t co = ct * f.slab_words;
+    v.mdctT += co; v.logfftT += co; v.logmdctT += co; v.noiseT += co; v.toneT += co; v.logmaskT += co;
+    v.epeakT += co; v.workT += co; v.npeakT += co; v.sumT += co; v.seedT += co; v.ampstackT += co;
+    v.posstackT += co; v.postT += co; v.floor_outT += co; v.iworkT += co; v.ntfixT += co;
+    const size_t so = stl * f.sb_slab_words;
+    v.partwordT += so; v.workvqT += so; v.m6defT += so; v.vqlenT += so; v.vqoffT += so;
+    v.vqcodeT += stl * f.vq_slab_words;
+    v.packetT += stl * 64 * (size_t)f.max_packet_bytes;
+    return v;
+}
+
 extern "C" int vbm_analysis_batch(vbm_encoder *e, int block_mode, int nsb, const int *stream_ids,
                                   const uint8_t *wflags, const float *d_pcm, uint8_t *d_packets,
                                   int *d_packet_bytes, void *stream)
@@ -260,71 +373,121 @@ extern "C" int vbm_analysis_batch(vbm_encoder *e, int block_mode, int nsb, const
         if (stream_ids[i] < 0 || stream_ids[i] >= e->S) return VBM_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     hipError_t err;
-    if ((err = hipMemcpyAsync(e->d_stream_id, stream_ids, nsb * sizeof(int), hipMemcpyHostToDevice, st)) != hipSuccess)
-        return vbm_set_hip_error(err, "hipMemcpyAsync(stream_ids)");
-    if ((err = hipMemcpyAsync(e->d_wflags, wflags, nsb, hipMemcpyHostToDevice, st)) != hipSuccess)
-        return vbm_set_hip_error(err, "hipMemcpyAsync(wflags)");
+    // stream ids / window flags: through pinned staging so the copy never stalls the host, and not
+    // at all when the caller repeats the previous lists (the steady state of a streaming encode)
+    if ((int)e->last_ids.size() != nsb || memcmp(e->last_ids.data(), stream_ids, nsb * sizeof(int)) ||
+        memcmp(e->last_flags.data(), wflags, nsb)) {
+        const int t = e->stage_turn;
+        e->stage_turn ^= 1;
+        (void)hipEventSynchronize(e->ev_stage[t]);   // the copy that last used this buffer has run
+        memcpy(e->h_ids[t], stream_ids, nsb * sizeof(int));
+        memcpy(e->h_flags[t], wflags, nsb);
+        if ((err = hipMemcpyAsync(e->d_stream_id, e->h_ids[t], nsb * sizeof(int), hipMemcpyHostToDevice, st)) != hipSuccess)
+            return vbm_set_hip_error(err, "hipMemcpyAsync(stream_ids)");
+        if ((err = hipMemcpyAsync(e->d_wflags, e->h_flags[t], nsb, hipMemcpyHostToDevice, st)) != hipSuccess)
+            return vbm_set_hip_error(err, "hipMemcpyAsync(wflags)");
+        (void)hipEventRecord(e->ev_stage[t], st);
+        e->last_ids.assign(stream_ids, stream_ids + nsb);
+        e->last_flags.assign(wflags, wflags + nsb);
+    }
 
     vbm_batch b;
     configure(e, b, block_mode, nsb, d_pcm);
     e->last_nsb = nsb;
     e->last_mode = block_mode;
 
+    // slices: multiples of 64 stream-blocks
+    const int tiles = (nsb + 63) / 64;
+    int nsplit = e->nsplit < tiles ? e->nsplit : tiles;
+    if (nsplit < 1) nsplit = 1;
+
     int W = b.W;
     int rc = 0;
-    const bool prof = e->profiling && e->events_used + kNumStages + 1 <= e->events.size();
-    size_t ev = e->events_used;
-#define MARK() do { if (prof) (void)hipEventRecord(e->events[ev++], st); } while (0)
+    const size_t ev_need = (size_t)2 * (kFront + (size_t)nsplit * kBack);
+    const bool prof = e->profiling && e->prof_calls < e->prof_max_calls && e->events_used + ev_need <= e->events.size();
+    // STAGE(k, q, launch): run `launch` on stream q, bracketed by a (begin, end) event pair when profiling
 #define RUN(x) do { rc = (x); if (rc) { g_vbm_err = std::string("launch failed: ") + #x; return VBM_EHIP; } } while (0)
+#define STAGE(k, q, launch)                                                                    \
+    do {                                                                                       \
+        size_t eb_ = 0;                                                                        \
+        if (prof) { eb_ = e->events_used++; (void)hipEventRecord(e->events[eb_], (q)); }       \
+        launch;                                                                                \
+        if (prof) {                                                                            \
+            size_t ee_ = e->events_used++;                                                     \
+            (void)hipEventRecord(e->events[ee_], (q));                                         \
+            e->spans.push_back({(k), eb_, ee_});                                               \
+        }                                                                                      \
+    } while (0)
     RUN(vbm_launch_spread_flags(&b, st));
-    MARK();
-    // loop A: window + MDCT, window + FFT + log spectrum (wave per block)
-    RUN(vbm_launch_window_mdct(b.pcm, b.mdct_bm, W ? b.wflags_cb : nullptr, vbm_setup_device_ptrs(e->H)->mdct_trig[W],
-                               vbm_setup_device_ptrs(e->H)->window[W], vbm_setup_device_ptrs(e->H)->window[0], b.N,
-                               s->blocksizes[0], 1, b.ncb, 0, st));
-    MARK();
-    RUN(vbm_launch_window_fft_log(b.pcm, b.logfft_bm, b.local_ampmax, W ? b.wflags_cb : nullptr,
-                                  vbm_setup_device_ptrs(e->H)->fft_wa[W], vbm_setup_device_ptrs(e->H)->window[W],
-                                  vbm_setup_device_ptrs(e->H)->window[0], b.N, s->blocksizes[0], b.ncb, st));
-    MARK();
-    RUN(vbm_launch_transpose_in(&b, st));
-    MARK();
-    // loop B: psychoacoustics + floor fit (lane per channel-block)
-    RUN(vbm_launch_prologue(&b, st));
-    MARK();
-    RUN(vbm_launch_noisemask(&b, st));
-    MARK();
-    RUN(vbm_launch_tonemask(&b, st));
-    MARK();
-    RUN(vbm_launch_mix(&b, st));
-    MARK();
-    RUN(vbm_launch_floor_fit(&b, st));
-    MARK();
-    // loop C: floor encode, couple/quantise, residue + packet assembly
-    RUN(vbm_launch_floor_encode(&b, st));
-    MARK();
-    RUN(vbm_launch_couple_quantize(&b, st));
-    MARK();
-    RUN(vbm_launch_pack(&b, st));
-    MARK();
-    if (d_packets)   // word-major tiles -> [nsb][max_packet_bytes] bytes (little-endian words)
-        RUN(vbm_launch_untranspose_i32((const int *)b.packetT, (int *)d_packets, e->max_packet_bytes / 4,
-                                       (size_t)(e->max_packet_bytes / 4) * 64, nsb, st));
-    if (d_packet_bytes) {
-        if ((err = hipMemcpyAsync(d_packet_bytes, b.packet_bytes, nsb * sizeof(int), hipMemcpyDeviceToDevice, st)) != hipSuccess)
-            return vbm_set_hip_error(err, "hipMemcpyAsync(packet_bytes)");
+    // loop A: window + MDCT, window + FFT + log spectrum (wave per block), whole batch
+    STAGE(0, st, RUN(vbm_launch_window_mdct(b.pcm, b.mdct_bm, W ? b.wflags_cb : nullptr,
+                                            vbm_setup_device_ptrs(e->H)->mdct_trig[W], vbm_setup_device_ptrs(e->H)->window[W],
+                                            vbm_setup_device_ptrs(e->H)->window[0], b.N, s->blocksizes[0], 1, b.ncb, 0, st)));
+    STAGE(1, st, RUN(vbm_launch_window_fft_log(b.pcm, b.logfft_bm, b.local_ampmax, W ? b.wflags_cb : nullptr,
+                                               vbm_setup_device_ptrs(e->H)->fft_wa[W], vbm_setup_device_ptrs(e->H)->window[W],
+                                               vbm_setup_device_ptrs(e->H)->window[0], b.N, s->blocksizes[0], b.ncb, st)));
+    STAGE(2, st, RUN(vbm_launch_transpose_in(&b, st)));
+
+    if (nsplit > 1 && (err = hipEventRecord(e->ev_fork, st)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
+    for (int part = 0; part < nsplit; part++) {
+        const int t0 = (int)((long)tiles * part / nsplit), t1 = (int)((long)tiles * (part + 1) / nsplit);
+        const int sb0 = t0 * 64, sb1 = (t1 * 64 < nsb) ? t1 * 64 : nsb;
+        if (sb1 <= sb0) continue;
+        hipStream_t q = st;
+        vbm_batch v = b;
+        if (nsplit > 1) {
+            q = e->sub[part];
+            v = slice_of(b, sb0, sb1 - sb0);
+            if ((err = hipStreamWaitEvent(q, e->ev_fork, 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
+        }
+        // loop B: psychoacoustics + floor fit (lane per channel-block).  The tone-mask branch reads only
+        // the log spectrum and the prologue's maxima, the noise-mask branch only the MDCT: they run side
+        // by side on two streams and meet at _vp_offset_and_mix.
+        STAGE(3, q, RUN(vbm_launch_prologue(&v, q)));
+        if (e->overlap_branches) {
+            hipStream_t qa = e->aux[part];
+            if ((err = hipEventRecord(e->ev_aux_fork[part], q)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
+            if ((err = hipStreamWaitEvent(qa, e->ev_aux_fork[part], 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
+            STAGE(5, qa, RUN(vbm_launch_tonemask(&v, qa)));
+            if ((err = hipEventRecord(e->ev_aux_join[part], qa)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
+            STAGE(4, q, RUN(vbm_launch_noisemask(&v, q)));
+            if ((err = hipStreamWaitEvent(q, e->ev_aux_join[part], 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
+        } else {
+            STAGE(4, q, RUN(vbm_launch_noisemask(&v, q)));
+            STAGE(5, q, RUN(vbm_launch_tonemask(&v, q)));
+        }
+        STAGE(6, q, RUN(vbm_launch_mix(&v, q)));
+        STAGE(7, q, RUN(vbm_launch_floor_fit(&v, q)));
+        // loop C: floor encode, couple/quantise, residue + packet assembly
+        STAGE(8, q, RUN(vbm_launch_floor_encode(&v, q)));
+        STAGE(9, q, RUN(vbm_launch_couple_quantize(&v, q)));
+        STAGE(10, q, RUN(vbm_launch_pack(&v, q)));
+        STAGE(11, q, {
+            if (d_packets)   // word-major tiles -> [nsb][max_packet_bytes] bytes (little-endian words)
+                RUN(vbm_launch_untranspose_i32((const int *)v.packetT,
+                                               (int *)(d_packets + (size_t)sb0 * e->max_packet_bytes),
+                                               e->max_packet_bytes / 4, (size_t)(e->max_packet_bytes / 4) * 64,
+                                               v.nsb, q));
+            if (d_packet_bytes) {
+                if ((err = hipMemcpyAsync(d_packet_bytes + sb0, v.packet_bytes, v.nsb * sizeof(int), hipMemcpyDeviceToDevice, q)) != hipSuccess)
+                    return vbm_set_hip_error(err, "hipMemcpyAsync(packet_bytes)");
+            }
+        });
+        if (nsplit > 1) {
+            if ((err = hipEventRecord(e->ev_join[part], q)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
+            if ((err = hipStreamWaitEvent(st, e->ev_join[part], 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
+        }
     }
-    MARK();
-    if (prof) e->events_used = ev;
+    if (prof) e->prof_calls++;
+#undef STAGE
 #undef RUN
-#undef MARK
     return VBM_OK;
 }
 
 extern "C" int vbm_encoder_profile_begin(vbm_encoder *e, int max_calls)
 {
     if (!e || max_calls <= 0) return VBM_EINVAL;
-    size_t need = (size_t)max_calls * (kNumStages + 1);
+    size_t need = (size_t)max_calls * 2 * (kFront + (size_t)e->nsplit * kBack);
     while (e->events.size() < need) {
         hipEvent_t ev;
         hipError_t err = hipEventCreate(&ev);
@@ -332,6 +495,9 @@ extern "C" int vbm_encoder_profile_begin(vbm_encoder *e, int max_calls)
         e->events.push_back(ev);
     }
     e->events_used = 0;
+    e->spans.clear();
+    e->prof_calls = 0;
+    e->prof_max_calls = max_calls;
     e->profiling = true;
     return VBM_OK;
 }
@@ -340,21 +506,20 @@ extern "C" int vbm_encoder_profile_end(vbm_encoder *e, float *stage_ms, int *nca
 {
     if (!e || !stage_ms) return VBM_EINVAL;
     e->profiling = false;
-    int calls = (int)(e->events_used / (kNumStages + 1));
     for (int k = 0; k < kNumStages; k++) stage_ms[k] = 0.f;
-    if (calls > 0) {
-        hipError_t err = hipEventSynchronize(e->events[e->events_used - 1]);
-        if (err != hipSuccess) return vbm_set_hip_error(err, "hipEventSynchronize");
-        for (int c = 0; c < calls; c++)
-            for (int k = 0; k < kNumStages; k++) {
-                float ms = 0.f;
-                (void)hipEventElapsedTime(&ms, e->events[(size_t)c * (kNumStages + 1) + k],
-                                          e->events[(size_t)c * (kNumStages + 1) + k + 1]);
-                stage_ms[k] += ms;
-            }
+    if (!e->spans.empty()) {
+        hipError_t err = hipDeviceSynchronize();
+        if (err != hipSuccess) return vbm_set_hip_error(err, "hipDeviceSynchronize");
+        for (const vbm_encoder::span &sp : e->spans) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e->events[sp.begin], e->events[sp.end]);
+            stage_ms[sp.stage] += ms;
+        }
     }
-    if (ncalls) *ncalls = calls;
+    if (ncalls) *ncalls = e->prof_calls;
     e->events_used = 0;
+    e->spans.clear();
+    e->prof_calls = 0;
     return VBM_OK;
 }
 

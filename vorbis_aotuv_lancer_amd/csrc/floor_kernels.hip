@@ -9,8 +9,17 @@
 //                   deviations (:856-942) happens in the packet kernel, in channel order.
 // Segment bounds, neighbour tables and sort order come from the floor look and are the same
 // in every lane; only the greedy split decisions diverge.
+//
+// floor1_fit looks at the mask only through dBquant(logmask[x]) and the test
+// logmdct[x] + twofitatten >= logmask[x].  k_floor_prep evaluates both once per bin and stores
+// them as one 16-bit word (quantised level | test << 15) in BLOCK-major rows qf_bm[channel-block][n]
+// (tile transpose through LDS).  The fit walks data-dependent bin ranges (inspect_error), so each
+// lane reads its own row: consecutive bins of a lane share cache lines, which the bin-major tiles
+// cannot offer.  k_floor_fit runs `lpw` lanes per wavefront (launch parameter) to put more
+// wavefronts in flight than ncb/64.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "batch.h"
 #include "kernels.h"
 
@@ -18,11 +27,32 @@
 
 namespace {
 
+// accumulate_fit's sums of one post segment; the y^2 sums of the source never reach the solution
+// (fit_line accumulates but does not read them) and are not kept
 struct lsfit_acc {
     int x0, x1;
-    int xa, ya, x2a, y2a, xya, an;
-    int xb, yb, x2b, y2b, xyb, bn;
+    int xa, ya, x2a, xya, an;
+    int xb, yb, x2b, xyb, bn;
 };
+
+// 8-bin register window over a lane's qf row: one 16-byte load per 8 consecutive bins
+struct qf_window {
+    const uint16_t *row;
+    int blk;
+    uint64_t lo, hi;
+};
+__device__ __forceinline__ int qf_get(qf_window &w, int i)
+{
+    const int blk = i >> 3;
+    if (blk != w.blk) {
+        w.blk = blk;
+        const uint4 v = *reinterpret_cast<const uint4 *>(w.row + (blk << 3));
+        w.lo = (uint64_t)v.x | ((uint64_t)v.y << 32);
+        w.hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
+    }
+    const uint64_t h = (i & 4) ? w.hi : w.lo;
+    return (int)((h >> ((i & 3) * 16)) & 0xffff);
+}
 
 __device__ __forceinline__ int render_point(int x0, int x1, int y0, int y1, int x)
 {
@@ -46,20 +76,19 @@ __device__ __forceinline__ int dBquant(float x)
     return i;
 }
 
-__device__ __forceinline__ int fit_line(const lsfit_acc *a, int fits, int *y0, int *y1, const vbm_floor *info)
+__device__ __forceinline__ int fit_line(const lsfit_acc *a, int fits, int *y0, int *y1, const float twofitweight)
 {
-    double xb = 0, yb = 0, x2b = 0, y2b = 0, xyb = 0, bn = 0;
+    double xb = 0, yb = 0, x2b = 0, xyb = 0, bn = 0;
     int i;
     int x0 = a[0].x0;
     int x1 = a[fits - 1].x1;
 
     for (i = 0; i < fits; i++) {
-        double weight = (double)((float)(a[i].bn + a[i].an) * info->twofitweight / (float)(a[i].an + 1)) + 1.;
+        double weight = (double)((float)(a[i].bn + a[i].an) * twofitweight / (float)(a[i].an + 1)) + 1.;
 
         xb += a[i].xb + a[i].xa * weight;
         yb += a[i].yb + a[i].ya * weight;
         x2b += a[i].x2b + a[i].x2a * weight;
-        y2b += a[i].y2b + a[i].y2a * weight;
         xyb += a[i].xyb + a[i].xya * weight;
         bn += a[i].bn + a[i].an * weight;
     }
@@ -68,7 +97,6 @@ __device__ __forceinline__ int fit_line(const lsfit_acc *a, int fits, int *y0, i
         xb += x0;
         yb += *y0;
         x2b += x0 * x0;
-        y2b += *y0 * *y0;
         xyb += *y0 * x0;
         bn++;
     }
@@ -77,7 +105,6 @@ __device__ __forceinline__ int fit_line(const lsfit_acc *a, int fits, int *y0, i
         xb += x1;
         yb += *y1;
         x2b += x1 * x1;
-        y2b += *y1 * *y1;
         xyb += *y1 * x1;
         bn++;
     }
@@ -111,19 +138,56 @@ __device__ __forceinline__ int post_Y(const int *A, const int *B, int pos)
     return (A[pos] + B[pos]) >> 1;
 }
 
-__global__ void k_floor_fit(vbm_batch b)
+// 64 channel-blocks x 64 bins per workgroup of 256 threads
+__global__ void k_floor_prep(vbm_batch b)
 {
-    const int lane = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lane >= b.ncb) return;
+    __shared__ uint16_t tile[64][66];
+    const vbm_setup *s = b.setup;
+    const vbm_map *map = &s->map[b.W];
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    {
+        const int c = c0 + tx;
+        float att = 0.f;
+        if (c < b.ncb) att = s->floor[map->floorsubmap[map->chmuxlist[c % b.ch]]].twofitatten;
+        const size_t tb = (size_t)(c >> 6) * b.slab_words + (c & 63);
+        for (int rr = ty; rr < 64; rr += 4) {
+            const int r = r0 + rr;
+            uint16_t w = 0;
+            if (c < b.ncb && r < b.n) {
+                const float fl = T(b.logmaskT, r);
+                w = (uint16_t)(dBquant(fl) | ((T(b.logmdctT, r) + att >= fl) ? 0x8000 : 0));
+            }
+            tile[rr][tx] = w;
+        }
+    }
+    __syncthreads();
+    for (int cc = ty; cc < 64; cc += 4) {
+        const int c = c0 + cc, r = r0 + tx;
+        if (c < b.ncb && r < b.n) b.qf_bm[(size_t)c * b.n + r] = tile[tx][cc];
+    }
+}
+
+__global__ void k_floor_fit(vbm_batch b, int lpw)
+{
+    const int lane = blockIdx.x * lpw + threadIdx.x;
+    if ((int)threadIdx.x >= lpw || lane >= b.ncb) return;
     const size_t tb = (size_t)(lane >> 6) * b.slab_words + (lane & 63);
+    qf_window qf;
+    qf.row = b.qf_bm + (size_t)lane * b.n;   // rows are 16-byte aligned: n is a multiple of 8
+    qf.blk = -1;
+    qf.lo = qf.hi = 0;
     const vbm_setup *s = b.setup;
     const int c = lane % b.ch;
     const vbm_map *map = &s->map[b.W];
     const vbm_floor *look = &s->floor[map->floorsubmap[map->chmuxlist[c]]];
     const vbm_floor *info = look;
-    const float *logmdct = b.logmdctT, *logmask = b.logmaskT;
     const int n = look->n;
     const int posts = look->posts;
+    // loop-invariant look fields in registers (the look is addressed per lane, the compiler cannot
+    // hoist these loads over the stores in the loops)
+    const float maxover = info->maxover, maxunder = info->maxunder, maxerr = info->maxerr;
+    const float twofitweight = info->twofitweight;
     int i, j;
     int nonzero = 0;
 
@@ -145,24 +209,24 @@ __global__ void k_floor_fit(vbm_batch b)
     // accumulate_fit over every minimal division (lib/floor1.c:625-628)
     for (int seg = 0; seg < posts - 1; seg++) {
         int x0 = look->sorted_index[seg], x1 = look->sorted_index[seg + 1];
-        int xa = 0, ya = 0, x2a = 0, y2a = 0, xya = 0, na = 0, xb = 0, yb = 0, x2b = 0, y2b = 0, xyb = 0, nb = 0;
+        int xa = 0, ya = 0, x2a = 0, xya = 0, na = 0, xb = 0, yb = 0, x2b = 0, xyb = 0, nb = 0;
         lsfit_acc *a = &fits[seg];
         a->x0 = x0;
         a->x1 = x1;
         if (x1 >= n) x1 = n - 1;
         for (i = x0; i <= x1; i++) {
-            float fl = T(logmask, i);
-            int quantized = dBquant(fl);
+            const int w = qf_get(qf, i);
+            const int quantized = w & 0x7fff;
             if (quantized) {
-                if (T(logmdct, i) + info->twofitatten >= fl) {
-                    xa += i; ya += quantized; x2a += i * i; y2a += quantized * quantized; xya += i * quantized; na++;
+                if (w & 0x8000) {
+                    xa += i; ya += quantized; x2a += i * i; xya += i * quantized; na++;
                 } else {
-                    xb += i; yb += quantized; x2b += i * i; y2b += quantized * quantized; xyb += i * quantized; nb++;
+                    xb += i; yb += quantized; x2b += i * i; xyb += i * quantized; nb++;
                 }
             }
         }
-        a->xa = xa; a->ya = ya; a->x2a = x2a; a->y2a = y2a; a->xya = xya; a->an = na;
-        a->xb = xb; a->yb = yb; a->x2b = x2b; a->y2b = y2b; a->xyb = xyb; a->bn = nb;
+        a->xa = xa; a->ya = ya; a->x2a = x2a; a->xya = xya; a->an = na;
+        a->xb = xb; a->yb = yb; a->x2b = x2b; a->xyb = xyb; a->bn = nb;
         nonzero += na;
     }
 
@@ -174,7 +238,7 @@ __global__ void k_floor_fit(vbm_batch b)
     {
         int y0 = -200;
         int y1 = -200;
-        fit_line(fits, posts - 1, &y0, &y1, info);
+        fit_line(fits, posts - 1, &y0, &y1, twofitweight);
 
         fit_valueA[0] = y0;
         fit_valueB[0] = y0;
@@ -209,7 +273,8 @@ __global__ void k_floor_fit(vbm_batch b)
                         int x = lx;
                         int y = ly;
                         int err = 0;
-                        int val = dBquant(T(logmask, x));
+                        int wv = qf_get(qf, x);
+                        int val = wv & 0x7fff;
                         int mse = 0;
                         int cnt = 0;
                         split = -1;
@@ -219,9 +284,9 @@ __global__ void k_floor_fit(vbm_batch b)
                         mse = (y - val);
                         mse *= mse;
                         cnt++;
-                        if (T(logmdct, x) + info->twofitatten >= T(logmask, x)) {
-                            if (y + info->maxover < val) split = 1;
-                            if (y - info->maxunder > val) split = 1;
+                        if (wv & 0x8000) {
+                            if (y + maxover < val) split = 1;
+                            if (y - maxunder > val) split = 1;
                         }
                         if (split < 0) {
                             while (++x < hx) {
@@ -232,30 +297,30 @@ __global__ void k_floor_fit(vbm_batch b)
                                 } else {
                                     y += base;
                                 }
-                                float mk = T(logmask, x);
-                                val = dBquant(mk);
+                                wv = qf_get(qf, x);
+                                val = wv & 0x7fff;
                                 mse += ((y - val) * (y - val));
                                 cnt++;
-                                if (T(logmdct, x) + info->twofitatten >= mk) {
+                                if (wv & 0x8000) {
                                     if (val) {
-                                        if (y + info->maxover < val) { split = 1; break; }
-                                        if (y - info->maxunder > val) { split = 1; break; }
+                                        if (y + maxover < val) { split = 1; break; }
+                                        if (y - maxunder > val) { split = 1; break; }
                                     }
                                 }
                             }
                         }
                         if (split < 0) {
-                            if (info->maxover * info->maxover / cnt > info->maxerr) split = 0;
-                            else if (info->maxunder * info->maxunder / cnt > info->maxerr) split = 0;
-                            else if (mse / cnt > info->maxerr) split = 1;
+                            if (maxover * maxover / cnt > maxerr) split = 0;
+                            else if (maxunder * maxunder / cnt > maxerr) split = 0;
+                            else if (mse / cnt > maxerr) split = 1;
                             else split = 0;
                         }
                     }
 
                     if (split) {
                         int ly0 = -200, ly1 = -200, hy0 = -200, hy1 = -200;
-                        int ret0 = fit_line(fits + lsortpos, sortpos - lsortpos, &ly0, &ly1, info);
-                        int ret1 = fit_line(fits + sortpos, hsortpos - sortpos, &hy0, &hy1, info);
+                        int ret0 = fit_line(fits + lsortpos, sortpos - lsortpos, &ly0, &ly1, twofitweight);
+                        int ret1 = fit_line(fits + sortpos, hsortpos - sortpos, &hy0, &hy1, twofitweight);
 
                         if (ret0) {
                             ly0 = ly;
@@ -443,7 +508,15 @@ static inline dim3 grid_for(int lanes) { return dim3((unsigned)((lanes + 63) / 6
 
 extern "C" int vbm_launch_floor_fit(const vbm_batch *b, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_floor_fit, grid_for(b->ncb), dim3(64), 0, st, *b);
+    static int lpw = 0;
+    if (!lpw) {
+        const char *e = getenv("VBM_FLOORFIT_LPW");   // tuning knob: lanes per wavefront of the greedy fit
+        lpw = e ? atoi(e) : 64;
+        if (lpw < 1 || lpw > 64) lpw = 64;
+    }
+    hipLaunchKernelGGL(k_floor_prep, dim3((unsigned)((b->ncb + 63) / 64), (unsigned)((b->n + 63) / 64)), dim3(256), 0,
+                       st, *b);
+    hipLaunchKernelGGL(k_floor_fit, dim3((unsigned)((b->ncb + lpw - 1) / lpw)), dim3(64), 0, st, *b, lpw);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 extern "C" int vbm_launch_floor_encode(const vbm_batch *b, hipStream_t st)

@@ -82,8 +82,26 @@ __device__ __forceinline__ int book_encode(const vbm_book *bk, int a, BitW &w)
     return bk->lengthlist[a];
 }
 
+// the fields of a book the VQ search reads per vector, fetched once per (partition, stage): the book
+// is addressed per lane, and the compiler cannot hoist its loads over the stores of the search loop
+struct book_regs {
+    int dim, minval, delta, quantvals, used, entries;
+    const signed char *lengthlist;
+    const uint32_t *codelist;
+    const int *used_point, *used_index;
+};
+__device__ __forceinline__ book_regs load_book(const vbm_book *book)
+{
+    book_regs r;
+    r.dim = book->dim; r.minval = book->minval; r.delta = book->delta; r.quantvals = book->quantvals;
+    r.used = book->used; r.entries = book->entries;
+    r.lengthlist = book->lengthlist; r.codelist = book->codelist;
+    r.used_point = book->used_point; r.used_index = book->used_index;
+    return r;
+}
+
 // local_book_besterror (lib/res0.c:316-378); a[] is the vector (dim <= 8) in registers
-__device__ __forceinline__ int besterror(const vbm_book *book, int *a)
+__device__ __forceinline__ int besterror(const book_regs *book, int *a)
 {
     const int dim = book->dim;
     int i, j, o;
@@ -288,6 +306,8 @@ __global__ void k_res_class(vbm_batch b, int sm, int nchunks)
     const int i0 = (int)((long)v.partvals * blockIdx.y / nchunks), i1 = (int)((long)v.partvals * (blockIdx.y + 1) / nchunks);
     int *partword = b.partwordT + SBT(sb);
     const int possible_partitions = r->partitions;
+    const int rbegin = r->begin;
+    const int *__restrict__ classmetric1 = r->classmetric1, *__restrict__ classmetric2 = r->classmetric2;
     int i, j, k;
 
     if (r->type == 2) {
@@ -297,7 +317,7 @@ __global__ void k_res_class(vbm_batch b, int sm, int nchunks)
         const int lsteps = (v.spp + nb - 1) / nb;   // the source advances l once per nb samples of a partition
         for (i = i0; i < i1; i++) {
             int magmax = 0, angmax = 0;
-            int l = r->begin / nb + i * lsteps;
+            int l = rbegin / nb + i * lsteps;
             for (j = 0; j < v.spp; j += nb, l++) {
                 int v0 = abs(IWC(v.chlist[0], l));
                 if (v0 > magmax) magmax = v0;
@@ -307,17 +327,17 @@ __global__ void k_res_class(vbm_batch b, int sm, int nchunks)
                 }
             }
             for (j = 0; j < possible_partitions - 1; j++)
-                if (magmax <= r->classmetric1[j] && angmax <= r->classmetric2[j]) break;
+                if (magmax <= classmetric1[j] && angmax <= classmetric2[j]) break;
             PW(0, i) = j;
         }
         // interleaved vector work[x] = in[x % nb][x / nb] over these partitions' samples
-        for (int x = r->begin + i0 * v.spp; x < r->begin + i1 * v.spp; x++)
+        for (int x = rbegin + i0 * v.spp; x < rbegin + i1 * v.spp; x++)
             work[(size_t)x * 64] = IWC(v.chlist[x % nb], x / nb);
     } else {
         // _01class (lib/res0.c:406-468): only the nonzero channels take part (:715-745)
         const float scale = (float)(100. / v.spp);
         for (i = i0; i < i1; i++) {
-            const int offset = i * v.spp + r->begin;
+            const int offset = i * v.spp + rbegin;
             for (j = 0; j < v.used; j++) {
                 int mx = 0, ent = 0;
                 for (k = 0; k < v.spp; k++) {
@@ -327,7 +347,7 @@ __global__ void k_res_class(vbm_batch b, int sm, int nchunks)
                 }
                 ent = (int)((float)ent * scale);
                 for (k = 0; k < possible_partitions - 1; k++)
-                    if (mx <= r->classmetric1[k] && (r->classmetric2[k] < 0 || ent < r->classmetric2[k])) break;
+                    if (mx <= classmetric1[k] && (classmetric2[k] < 0 || ent < classmetric2[k])) break;
                 PW(j, i) = k;
             }
         }
@@ -360,7 +380,8 @@ __global__ void k_res_vq(vbm_batch b, int sm, int nchunks)
                 int bits = 0;
                 const int bi = (r->secondstages[cls] & (1 << st)) ? r->partbook[cls][st] : -1;
                 if (bi >= 0) {
-                    const vbm_book *book = &s->book[bi];
+                    const book_regs bk = load_book(&s->book[bi]);
+                    const book_regs *book = &bk;
                     const int dim = book->dim;
                     const int step = v.spp / dim;
                     uint64_t *sl = slot + (st * stage_slots + (size_t)j * veclen + offset) * 64;
@@ -496,7 +517,7 @@ extern "C" int vbm_launch_pack(const vbm_batch *b, hipStream_t st)
     if (hipMemsetAsync(b->packetT, 0, (size_t)tiles * 64 * b->max_packet_bytes, st) != hipSuccess) return -2;
     hipLaunchKernelGGL(k_pack_head, dim3(tiles), dim3(64), 0, st, *b);
     for (int sm = 0; sm < b->pack_submaps; sm++) {
-        int nchunks = b->pack_partvals[sm] < 16 ? b->pack_partvals[sm] : 16;
+        int nchunks = b->pack_partvals[sm] < 32 ? b->pack_partvals[sm] : 32;
         if (nchunks < 1) nchunks = 1;
         hipLaunchKernelGGL(k_res_class, dim3(tiles, (unsigned)nchunks), dim3(64), 0, st, *b, sm, nchunks);
         hipLaunchKernelGGL(k_res_vq, dim3(tiles, (unsigned)nchunks), dim3(64), 0, st, *b, sm, nchunks);

@@ -18,6 +18,7 @@
 // wave-uniform.  Compiled with -ffp-contract=off; `double` where the C source promotes.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "batch.h"
 #include "kernels.h"
 
@@ -29,6 +30,10 @@
 
 namespace {
 
+// NOTE on setup reads inside loops: the setup lives in global memory behind b.setup, and the compiler
+// must assume that the kernels' own global stores may alias it, so `p->field` inside a loop is
+// re-loaded (scalar load + wait) every iteration.  Loop-invariant fields and table pointers are
+// therefore copied into locals before the hot loops.
 __device__ __forceinline__ const vbm_psy *psy_of(const vbm_batch &b)
 {
     // psy_look = b->psy + blocktype + (W ? 2 : 0)   (lib/mapping0.c:764) == psy[block_mode]
@@ -234,6 +239,7 @@ __global__ void k_nm_solve(vbm_batch b, int nchunks)
     const float offset = (PASS == 1) ? 140.f : 0.f;
     const int fixed = (PASS == 1) ? -1 : p->noisewindowfixed;
     const hy_bounds h = hybrid_bounds(p, fixed);
+    const int *__restrict__ bark_lo = p->bark_lo, *__restrict__ bark_hi = p->bark_hi;   // hoisted: see note at psy_of
     const float *__restrict__ sum = b.sumT;
     float *__restrict__ noise = b.noiseT;
     float *__restrict__ work = b.workT;
@@ -243,7 +249,7 @@ __global__ void k_nm_solve(vbm_batch b, int nchunks)
     hy_abd tail; tail.A = 0.f; tail.B = 0.f; tail.D = 1.f;
     if (c1 > h.i2 && h.i2 > 0) {
         const int t = h.i2 - 1;
-        tail = hybrid_abd(sum, tb, n, p->bark_lo[t], p->bark_hi[t], t < h.i1);
+        tail = hybrid_abd(sum, tb, n, bark_lo[t], bark_hi[t], t < h.i1);
     }
     hy_abd ftail = tail;
     if (fixed > 0 && c1 > h.f2 && h.f2 > 0) {
@@ -254,7 +260,7 @@ __global__ void k_nm_solve(vbm_batch b, int nchunks)
     for (int i = c0; i < c1; i++) {
         const float x = (float)i;   // the source's x += 1.f from 0 is exact below 2^24
         hy_abd v = tail;
-        if (i < h.i2) v = hybrid_abd(sum, tb, n, p->bark_lo[i], p->bark_hi[i], i < h.i1);
+        if (i < h.i2) v = hybrid_abd(sum, tb, n, bark_lo[i], bark_hi[i], i < h.i1);
         float R = (v.A + x * v.B) / v.D;
         if (R < 0.f) R = 0.f;
         float nz = R - offset;
@@ -277,14 +283,14 @@ __global__ void k_nm_solve(vbm_batch b, int nchunks)
     }
 }
 
-// aoTuV M7, lib/psy.c:3645-3768.  temp/inmod: 256-entry per-lane scratch carved from seedT/ampstackT
+// aoTuV M7, lib/psy.c:3645-3768.  temp/inmod: 256-entry per-lane scratch (ntfixT)
 __device__ __forceinline__ void ntfix(const vbm_batch &b, const vbm_psy *p, int lane, const float *spectral, float *noise)
 {
     const size_t tb = TB(b, lane);
     int i, j, k;
     int n = p->n;
     int nx = p->tonefix_end;
-    float *temp = b.seedT, *inmod = b.ampstackT;   // both have >= 256 rows (total_octave_lines >= 585)
+    float *temp = b.ntfixT, *inmod = b.ntfixT + (size_t)256 * 64;
     float limit = fabsf(p->noiseoffset[1][0]);
 
     if (!nx) return;
@@ -404,6 +410,10 @@ __global__ void k_nm_post(vbm_batch b, int nchunks)
 
     float *logmdct = b.logmdctT, *logmask = b.noiseT, *work = b.workT, *epeak = b.epeakT, *npeak = b.npeakT;
     const float noise_compand_level = b.st.lowcomp[col];
+    const float *__restrict__ noisecompand = p->noisecompand, *__restrict__ noisecompand_high = p->noisecompand_high;
+    const int *__restrict__ stn_compand = s->stn_compand;
+    const float *__restrict__ noiseoffset1 = p->noiseoffset[1];
+    const int min_nn_lp = p->min_nn_lp;
 
     // noise compand & aoTuV M5 extension & pre-store tone peak
     {
@@ -413,12 +423,12 @@ __global__ void k_nm_post(vbm_batch b, int nchunks)
             if (dB >= VBM_NOISE_COMPAND_LEVELS) dB = VBM_NOISE_COMPAND_LEVELS - 1;
             if (dB < 0) dB = 0;
             const float wv = T(work, i);
-            T(epeak, i) = wv + s->stn_compand[dB];
+            T(epeak, i) = wv + stn_compand[dB];
             if (i < thter)
-                T(logmask, i) = wv + p->noisecompand[dB] -
-                                ((p->noisecompand[dB] - p->noisecompand_high[dB]) * noise_compand_level);
+                T(logmask, i) = wv + noisecompand[dB] -
+                                ((noisecompand[dB] - noisecompand_high[dB]) * noise_compand_level);
             else
-                T(logmask, i) = wv + p->noisecompand[dB];
+                T(logmask, i) = wv + noisecompand[dB];
         }
     }
 
@@ -427,8 +437,8 @@ __global__ void k_nm_post(vbm_batch b, int nchunks)
     // reduction of post-echo (postprocessing of aoTuV M2)
     const float poste = b.poste[lane];
     if (poste > 0) {
-        for (k = k0, i = c0; k < k1 && i < p->min_nn_lp; i += partition, k++) {
-            float temp = VMIN(VMIN(poste, 30.f), p->noiseoffset[1][i] + 30.f);
+        for (k = k0, i = c0; k < k1 && i < min_nn_lp; i += partition, k++) {
+            float temp = VMIN(VMIN(poste, 30.f), noiseoffset1[i] + 30.f);
             if (temp <= 0) continue;
             T(npeak, k) = -1.f;
             for (j = 0; j < partition; j++) T(logmask, i + j) -= temp;
@@ -436,9 +446,9 @@ __global__ void k_nm_post(vbm_batch b, int nchunks)
     }
 
     // M8
-    for (k = k0, i = c0; k < k1 && i < p->min_nn_lp; i += partition, k++) {
+    for (k = k0, i = c0; k < k1 && i < min_nn_lp; i += partition, k++) {
         const float nt = 4;
-        float o = p->noiseoffset[1][i + partition - 1] + 6;
+        float o = noiseoffset1[i + partition - 1] + 6;
         float me = 0;
         float avge = 0;
 
@@ -521,23 +531,26 @@ __global__ void k_tm_stamp(vbm_batch b, int nchunks)
     if (att < p->ath_maxatt) att = p->ath_maxatt;
     const float dBoffset = p->max_curve_dB - global_specmax;
     const int tn = p->total_octave_lines, linesper = p->eighth_octave_lines;
+    const int *__restrict__ group_start = p->group_start, *__restrict__ octave = p->octave;
+    const float *__restrict__ ath = p->ath, *__restrict__ tonecurves = p->tonecurves;
+    const int shiftoc = p->shiftoc, firstoc = p->firstoc;
 
     // seed_loop (lib/psy.c:719-771), seed_curve (:652-717)
     for (int g = g0; g < g1; g++) {
-        const int s0 = p->group_start[g], s1 = p->group_start[g + 1];
+        const int s0 = group_start[g], s1 = group_start[g + 1];
         float max = T(f, s0);
         for (int i = s0 + 1; i < s1; i++) {
             float v = T(f, i);
             if (v > max) max = v;
         }
         const int last = s1 - 1;
-        if (max + 6.f > p->ath[last] + att) {
-            long oc = p->octave[last];
-            oc = oc >> p->shiftoc;
+        if (max + 6.f > ath[last] + att) {
+            long oc = octave[last];
+            oc = oc >> shiftoc;
             if (oc >= VBM_P_BANDS) oc = VBM_P_BANDS - 1;
             if (oc < 0) oc = 0;
-            const float *curves = p->tonecurves + (size_t)oc * VBM_P_LEVELS * (VBM_EHMER_MAX + 2);
-            const int ocl = p->octave[last] - p->firstoc;
+            const float *curves = tonecurves + (size_t)oc * VBM_P_LEVELS * (VBM_EHMER_MAX + 2);
+            const int ocl = octave[last] - firstoc;
             int choice = (int)(((double)(max + dBoffset) - 30.) * (double).1f);   // P_LEVEL_0 = 30. (double)
             choice = VMAX(choice, 0);
             choice = VMIN(choice, VBM_P_LEVELS - 1);
@@ -554,10 +567,11 @@ __global__ void k_tm_stamp(vbm_batch b, int nchunks)
     }
 }
 
-__global__ void k_tm_chase(vbm_batch b)
+__global__ void k_tm_chase(vbm_batch b, int lpw)
 {
-    const int lane = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lane >= b.ncb) return;
+    // `lpw` lanes per wavefront: the walk is latency-bound, fewer lanes per wave = more waves in flight
+    const int lane = blockIdx.x * lpw + threadIdx.x;
+    if ((int)threadIdx.x >= lpw || lane >= b.ncb) return;
     const size_t tb = TB(b, lane);
     const vbm_psy *p = psy_of(b);
     float *seed = b.seedT, *ampstack = b.ampstackT;
@@ -652,25 +666,28 @@ __global__ void k_tm_apply(vbm_batch b, int nchunks)
 
     float att = b.local_ampmax[lane] + p->ath_adjatt;
     if (att < p->ath_maxatt) att = p->ath_maxatt;
+    const int *__restrict__ seg_p0 = p->seg_p0, *__restrict__ seg_p1 = p->seg_p1;
+    const float *__restrict__ ath = p->ath;
+    const float tone_abs_limit = p->tone_abs_limit;
 
     int q0 = -2, q1 = -2;
     float minV = 0.f;
     for (int i = c0; i < c1; i++) {
-        const int p0 = p->seg_p0[i], p1 = p->seg_p1[i];
+        const int p0 = seg_p0[i], p1 = seg_p1[i];
         if (p0 != q0 || p1 != q1) {
             q0 = p0; q1 = p1;
             if (p0 < 0) {
                 minV = T(seed, tn - 1);
             } else {
                 minV = T(seed, p0);
-                if (minV > p->tone_abs_limit) minV = p->tone_abs_limit;
+                if (minV > tone_abs_limit) minV = tone_abs_limit;
                 for (int pos = p0 + 1; pos <= p1; pos++) {
                     float sv = T(seed, pos);
                     if ((sv > NEGINF && sv < minV) || minV == NEGINF) minV = sv;
                 }
             }
         }
-        float v = p->ath[i] + att;
+        float v = ath[i] + att;
         if (v < minV) v = minV;
         T(flr, i) = v;
     }
@@ -816,12 +833,15 @@ __global__ void k_mix(vbm_batch b, int nchunks)
         if (p->normal_thresh > 1.) m4_start = 9999;
     }
 
+    const float *__restrict__ noiseoffset = p->noiseoffset[offset_select];
+    const float noisemaxsupp = p->noisemaxsupp, m_val = p->m_val;
+    const int tonecomp_endp = p->tonecomp_endp, m3n0 = p->m3n[0], m3n1 = p->m3n[1], m3n2 = p->m3n[2];
     for (i = i0; i < i1; i++) {
-        float val = T(noise, i) + p->noiseoffset[offset_select][i];
+        float val = T(noise, i) + noiseoffset[i];
         float tval = T(tone, i) + toneatt;
         const float lm = T(logmdct, i);
         if (i <= m4_start) tval -= low_compand;
-        if (val > p->noisemaxsupp) val = p->noisemaxsupp;
+        if (val > noisemaxsupp) val = noisemaxsupp;
 
         // M3 MAIN
         if (mp3.sw) {
@@ -836,7 +856,7 @@ __global__ void k_mix(vbm_batch b, int nchunks)
                     if (mp3.mdctbuf_flag == 1) TEMP(i) = lm;
                     if (lm > last) rate_mod = mp3.noise_rate;
                     else rate_mod = mp3.noise_rate_low;
-                    if (!impadnum && (i < p->tonecomp_endp) && ((val - last) > 20.f)) {
+                    if (!impadnum && (i < tonecomp_endp) && ((val - last) > 20.f)) {
                         float dBsub = (lm - last);
                         if (dBsub > 25.f) {
                             toneac = 1;
@@ -849,11 +869,11 @@ __global__ void k_mix(vbm_batch b, int nchunks)
                             }
                         }
                     }
-                    if (i > p->m3n[0]) {
+                    if (i > m3n0) {
                         mainth = 30.f;
-                    } else if (i > p->m3n[1]) {
+                    } else if (i > m3n1) {
                         mainth = 20.f;
-                    } else if (i > p->m3n[2]) {
+                    } else if (i > m3n2) {
                         mainth = 10.f;
                         rate_mod *= .5f;
                     } else {
@@ -894,10 +914,10 @@ __global__ void k_mix(vbm_batch b, int nchunks)
             m1_coeffi = (float)-17.2;
             val = val - lm;
             if (val > m1_coeffi) {
-                m1_de = (float)(1.0 - ((double)(val - m1_coeffi) * 0.005 * (double)p->m_val));
+                m1_de = (float)(1.0 - ((double)(val - m1_coeffi) * 0.005 * (double)m_val));
                 if (m1_de < 0) m1_de = (float)0.0001;
             } else
-                m1_de = (float)(1.0 - ((double)(val - m1_coeffi) * 0.0003 * (double)p->m_val));
+                m1_de = (float)(1.0 - ((double)(val - m1_coeffi) * 0.0003 * (double)m_val));
             T(mdct, i) *= m1_de;
         }
     }
@@ -969,7 +989,13 @@ extern "C" int vbm_launch_tonemask(const vbm_batch *b, hipStream_t st)
     const int nchunks = bin_chunks(b);
     hipLaunchKernelGGL(k_tm_init, dim3(tiles, (unsigned)nchunks), dim3(64), 0, st, *b, nchunks);
     hipLaunchKernelGGL(k_tm_stamp, dim3(tiles, (unsigned)nchunks), dim3(64), 0, st, *b, nchunks);
-    hipLaunchKernelGGL(k_tm_chase, dim3(tiles), dim3(64), 0, st, *b);
+    static int lpw = 0;
+    if (!lpw) {
+        const char *e = getenv("VBM_CHASE_LPW");   // tuning knob
+        lpw = e ? atoi(e) : 64;
+        if (lpw < 1 || lpw > 64) lpw = 64;
+    }
+    hipLaunchKernelGGL(k_tm_chase, dim3((unsigned)((b->ncb + lpw - 1) / lpw)), dim3(64), 0, st, *b, lpw);
     hipLaunchKernelGGL(k_tm_apply, dim3(tiles, (unsigned)nchunks), dim3(64), 0, st, *b, nchunks);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

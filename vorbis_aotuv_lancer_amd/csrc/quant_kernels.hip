@@ -117,7 +117,14 @@ __device__ __forceinline__ float min_indemnity_dipole_hypot(const float a, const
 }
 
 // q / out / r / res / f / flags are this channel's partition scratch; out is strided (bin-major)
-__device__ __forceinline__ float noise_normalize(const vbm_psy *p, const int limit, float *r, float *q, const float *f, float *res,
+// loop-invariant psy fields of noise_normalize, read once per kernel (the compiler cannot hoist
+// setup loads over the kernel's global stores)
+struct nn_consts {
+    int normal_p, normal_start;
+    double normal_thresh;
+};
+
+__device__ __forceinline__ float noise_normalize(const nn_consts *p, const int limit, float *r, float *q, const float *f, float *res,
                                  const int *flags, float acc, const float nepeak, const int i, const int n,
                                  int *out, const size_t ostride)
 {
@@ -289,6 +296,11 @@ __global__ void k_couple_quantize(vbm_batch b, int nchunks)
     float postpoint_x = (float)s->stereo_threshholds_X[s->coupling_postpointamp[blobno]];
     float prae;
     const int sliding_lowpass = s->sliding_lowpass[b.W][blobno];
+    nn_consts nn;
+    nn.normal_p = p->normal_p; nn.normal_start = p->normal_start; nn.normal_thresh = p->normal_thresh;
+    const float *__restrict__ fromdB = s->fromdB;
+    const int tonefix_end = p->tonefix_end;
+    const int coupling_steps = vi->coupling_steps;
     int lowpassr;
     {
         // lib/mapping0.c:778-781
@@ -339,7 +351,7 @@ __global__ void k_couple_quantize(vbm_batch b, int nchunks)
         for (k = 0; k < ch; k++) {
             if (nz[k]) {
                 for (j = 0; j < jn; j++) {
-                    floor[k][j] = s->fromdB[IW(k, i + j)];
+                    floor[k][j] = fromdB[IW(k, i + j)];
                     mdl[j] = MD(k, i + j);
                     enp[j] = EP(k, i + j);
                 }
@@ -353,7 +365,7 @@ __global__ void k_couple_quantize(vbm_batch b, int nchunks)
                     floor[k][j] *= floor[k][j];
                 }
 
-                acc[track] = noise_normalize(p, limit, raw[k], quant[k], floor[k], res[k], nullptr, acc[track],
+                acc[track] = noise_normalize(&nn, limit, raw[k], quant[k], floor[k], res[k], nullptr, acc[track],
                                              NP(k, pi), i, jn, &IW(k, i), 64);
             } else {
                 for (j = 0; j < jn; j++) {
@@ -370,7 +382,7 @@ __global__ void k_couple_quantize(vbm_batch b, int nchunks)
         }
 
         // coupling
-        for (step = 0; step < vi->coupling_steps; step++) {
+        for (step = 0; step < coupling_steps; step++) {
             int Mi = vi->coupling_mag[step];
             int Ai = vi->coupling_ang[step];
             float *reM = raw[Mi], *reA = raw[Ai];
@@ -384,7 +396,7 @@ __global__ void k_couple_quantize(vbm_batch b, int nchunks)
                 nz[Mi] = nz[Ai] = 1;
 
                 // M6
-                if (p->tonefix_end > i) {
+                if (tonefix_end > i) {
                     int rp = 0, pp = 0, ap;
                     float residue_def = 0;
 
@@ -402,7 +414,7 @@ __global__ void k_couple_quantize(vbm_batch b, int nchunks)
                         float temp_def = residue_def = residue_def / ap;
                         float side = side_resdef[step];
                         if (b.couple_parallel)
-                            side = (pi > 0) ? m6[((size_t)(pi - 1) * vi->coupling_steps + step) * 64] : -1.f;
+                            side = (pi > 0) ? m6[((size_t)(pi - 1) * coupling_steps + step) * 64] : -1.f;
                         if (side > 0)
                             residue_def = (float)((double)temp_def * 0.5 + (double)side * 0.5);
                         side_resdef[step] = temp_def;
@@ -434,7 +446,7 @@ __global__ void k_couple_quantize(vbm_batch b, int nchunks)
                         } else {
                             // lossy (point) coupling
                             float hpL, hpH;
-                            if (vi->coupling_steps == 1 || step == 3) {
+                            if (coupling_steps == 1 || step == 3) {
                                 hpL = .18f;
                                 hpH = .12f;
                             } else {
@@ -460,7 +472,7 @@ __global__ void k_couple_quantize(vbm_batch b, int nchunks)
                     floorM[j] = floorA[j] = floorM[j] + floorA[j];
                 }
                 if (pointflag)
-                    acc[track] = noise_normalize(p, limit, raw[Mi], quant[Mi], floor[Mi], res[Mi], flag[Mi], acc[track],
+                    acc[track] = noise_normalize(&nn, limit, raw[Mi], quant[Mi], floor[Mi], res[Mi], flag[Mi], acc[track],
                                                  NP(Mi, pi), i, jn, &IW(Mi, i), 64);
                 track++;
             }
@@ -491,7 +503,7 @@ extern "C" int vbm_launch_couple_quantize(const vbm_batch *b, hipStream_t st)
     if (b->couple_parallel) {
         if (b->couple_m6parts > 0)
             hipLaunchKernelGGL(k_couple_m6stats, dim3(tiles, (unsigned)b->couple_m6parts), dim3(64), 0, st, *b);
-        nchunks = b->couple_parts < 16 ? (b->couple_parts > 0 ? b->couple_parts : 1) : 16;
+        nchunks = b->couple_parts < 32 ? (b->couple_parts > 0 ? b->couple_parts : 1) : 32;
     }
     hipLaunchKernelGGL(k_couple_quantize, dim3(tiles, (unsigned)nchunks), dim3(64), 0, st, *b, nchunks);
     return hipGetLastError() == hipSuccess ? 0 : -2;

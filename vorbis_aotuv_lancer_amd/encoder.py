@@ -93,6 +93,14 @@ class Encoder:
               "vbm_encoder_fetch")
         return out
 
+    def set_sub_batches(self, n):
+        """Slices of a batch that run on separate internal HIP streams after the transforms."""
+        check(lib.vbm_encoder_set_sub_batches(self._h, n), "vbm_encoder_set_sub_batches")
+
+    @property
+    def sub_batches(self):
+        return lib.vbm_encoder_sub_batches(self._h)
+
     def profile_begin(self, max_calls):
         check(lib.vbm_encoder_profile_begin(self._h, max_calls), "vbm_encoder_profile_begin")
 
