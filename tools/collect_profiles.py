@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/final/ (tools/gpu_profile.sh) into the committed artifacts:
+   profiles/<round>/bench_default.json, kernel_stats.csv, pmc_hbm_traffic.csv and profiles/pmc_traffic.json
+   (per-stage HBM bytes per launch that bench.py reports as roofline.traffic)."""
+import csv, json, os, re, sqlite3, sys, collections, statistics
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(ROOT, "gpurun_out", "final")
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+dst = os.path.join(ROOT, "profiles", rnd)
+os.makedirs(dst, exist_ok=True)
+
+STAGE_OF = [("k_window_mdct", "window_mdct"), ("k_window_fft_log", "window_fft_log"), ("k_to_tiled", "transpose"),
+            ("k_prologue", "prologue"), ("k_nm_", "noisemask"), ("k_tm_", "tonemask"), ("k_mix", "offset_and_mix"),
+            ("k_floor_prep", "floor_fit"), ("k_floor_fit", "floor_fit"), ("k_floor_encode", "floor_encode"),
+            ("k_couple_", "couple_quantize"), ("k_pack_head", "pack"), ("k_res_", "pack"), ("k_from_tiled", "packet_out")]
+
+def short(name):
+    name = re.sub(r"\(.*\)", "", name)
+    return re.sub(r"^_ZN12_GLOBAL__N_1\d+", "", name)
+
+def stage_of(k):
+    for pre, st in STAGE_OF:
+        if k.startswith(pre): return st
+    return None
+
+def open_db(sub):
+    d = os.path.join(src, sub)
+    f = [x for x in os.listdir(d) if x.endswith(".db")][0]
+    db = sqlite3.connect(os.path.join(d, f))
+    tabs = [r[0] for r in db.execute("select name from sqlite_master where type='table'")]
+    return db, (lambda p: [t for t in tabs if t.startswith(p)][0])
+
+# 1. bench line
+line = [l for l in open(os.path.join(src, "bench.json")) if l.startswith("{")][-1]
+bench = json.loads(line)
+json.dump(bench, open(os.path.join(dst, "bench_default.json"), "w"), indent=1)
+
+# 2. kernel stats of the same command
+db, tab = open_db("stats")
+kd, ks = tab("rocpd_kernel_dispatch"), tab("rocpd_info_kernel_symbol")
+rows = db.execute(f"select s.kernel_name, count(*), avg(d.end-d.start), min(d.end-d.start), max(d.end-d.start), sum(d.end-d.start) "
+                  f"from {kd} d join {ks} s on d.kernel_id=s.id group by s.kernel_name order by 6 desc").fetchall()
+tot = sum(r[5] for r in rows)
+with open(os.path.join(dst, "kernel_stats.csv"), "w", newline="") as f:
+    w = csv.writer(f)
+    w.writerow(["kernel", "stage", "calls", "avg_ns", "min_ns", "max_ns", "total_ns", "percent"])
+    for name, c, a, mn, mx, t in rows:
+        k = short(name)
+        w.writerow([k, stage_of(k) or "", c, round(a), mn, mx, t, round(100 * t / tot, 2)])
+
+# 3. HBM traffic per kernel and per stage: (2*FETCH_SIZE + WRITE_SIZE) KiB, MI355X_MICROARCH.md HBM section
+def pmc(sub, ctr):
+    db, tab = open_db(sub)
+    kd, ks, pe, pi = tab("rocpd_kernel_dispatch"), tab("rocpd_info_kernel_symbol"), tab("rocpd_pmc_event"), tab("rocpd_info_pmc")
+    q = (f"select s.kernel_name, x.v from (select e.event_id eid, sum(e.value) v from {pe} e join {pi} i on i.id=e.pmc_id "
+         f"where i.name='{ctr}' group by e.event_id) x join {kd} d on d.event_id=x.eid join {ks} s on d.kernel_id=s.id")
+    per = collections.defaultdict(list)
+    for name, v in db.execute(q): per[short(name)].append(v)
+    return {k: (statistics.median(v), len(v)) for k, v in per.items()}
+
+fetch, write = pmc("fetch", "FETCH_SIZE"), pmc("write", "WRITE_SIZE")
+stage_bytes = collections.defaultdict(float)
+with open(os.path.join(dst, "pmc_hbm_traffic.csv"), "w", newline="") as f:
+    w = csv.writer(f)
+    w.writerow(["kernel", "stage", "launches_sampled", "FETCH_SIZE_KiB_median", "WRITE_SIZE_KiB_median", "hbm_bytes_per_launch"])
+    for k in sorted(set(fetch) | set(write)):
+        st = stage_of(k)
+        if not st: continue
+        fk, n = fetch.get(k, (0, 0)); wk, _ = write.get(k, (0, 0))
+        by = (2 * fk + wk) * 1024
+        # kernels that run twice per stage launch (k_to_tiled: mdct + logfft; templates listed separately)
+        mult = 2 if k.startswith("k_to_tiled") else 1
+        stage_bytes[st] += by * mult
+        w.writerow([k, st, n, fk, wk, round(by)])
+cfg = bench["config"]
+json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `bench.py --steps 6 --warmup 2`; "
+                   "hbm bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB (gfx950 FETCH_SIZE tallies 128-B requests at 64 B, "
+                   "MI355X_MICROARCH.md HBM section); median over launches, summed over the kernels of a stage.",
+           "channel_blocks_per_step": cfg["channel_blocks_per_step"], "sub_batches": bench.get("sub_batches", 1),
+           "hbm_bytes_per_launch": {k: round(v) for k, v in stage_bytes.items()}},
+          open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+print("wrote", dst, "and profiles/pmc_traffic.json")
+for k, v in sorted(stage_bytes.items(), key=lambda x: -x[1]): print(f"  {k:18s} {v/1e6:10.1f} MB/launch")
