@@ -151,6 +151,45 @@ int vbm_encoder_fetch(vbm_encoder *enc, const char *name, void *d_out, long *row
 int vbm_encoder_set_sub_batches(vbm_encoder *enc, int n);
 int vbm_encoder_sub_batches(const vbm_encoder *enc);
 
+/* ---- stream front end --------------------------------------------------------
+ * What libvorbis does between the application's PCM and vorbis_analysis(), for all `nstreams` of
+ * an encoder at once and on the device:
+ *   vorbis_analysis_buffer + vorbis_analysis_wrote   (reference include/vorbis/codec.h:192-193,
+ *                                                     lib/block.c:405-553: pre_amplitude, LPC
+ *                                                     extrapolation of stream start and end)
+ *   vorbis_analysis_blockout                          (codec.h:194, lib/block.c:557-812) with the
+ *                                                     envelope detector that picks the block sizes
+ *                                                     (lib/envelope.c:101-728)
+ * followed by vbm_analysis_batch on the blocks that came out.  Usage, mirroring
+ * examples/encoder_example.c:190-235:
+ *     vbm_frontend_write(fe, d_pcm, vals, q);                       // every stream gets `vals` samples
+ *     do vbm_frontend_encode_round(fe, d_pkt, d_len, info, &n, q);  // <= 1 block per stream per round
+ *     while (n > 0);
+ *     ... vbm_frontend_finish(fe, ids, k, q) = vorbis_analysis_wrote(vd, 0), then rounds until n == 0.
+ * The block sequence (lW, W, nW, block type, granulepos, packetno, e_o_s) and the packets are those
+ * of the reference's scalar build for the same PCM.  d_pcm: device float, [nstreams][channels][vals].
+ * encode_round: packets of the round in d_packets[k][max_packet_bytes] / d_packet_bytes[k],
+ * k < *nblocks, described by info[k] (host array of nstreams entries); blocks are grouped by block
+ * type, streams ascending inside a group.  The call synchronises `stream` once (it reads the
+ * block decisions back to choose the batches).  Errors: VBM_EINVAL for writes that would overrun
+ * the PCM buffer (the reference's OV_EINVAL, lib/block.c:540) or follow finish. */
+typedef struct vbm_frontend vbm_frontend;
+typedef struct vbm_packet_info {
+    int stream;                 /* stream index */
+    int block_mode;             /* 0 impulse, 1 padding, 2 transition, 3 long */
+    int lW, W, nW;              /* vb->lW, vb->W, vb->nW */
+    int eos;                    /* op.e_o_s */
+    long long granulepos;       /* op.granulepos */
+    long long packetno;         /* op.packetno (audio packets start at 3) */
+} vbm_packet_info;
+int vbm_frontend_create(vbm_frontend **fe, vbm_encoder *enc);
+void vbm_frontend_destroy(vbm_frontend *fe);
+int vbm_frontend_reset(vbm_frontend *fe);
+int vbm_frontend_write(vbm_frontend *fe, const float *d_pcm, int vals, void *stream);
+int vbm_frontend_finish(vbm_frontend *fe, const int *stream_ids, int n, void *stream);
+int vbm_frontend_encode_round(vbm_frontend *fe, uint8_t *d_packets, int *d_packet_bytes,
+                              vbm_packet_info *info, int *nblocks, void *stream);
+
 /* Per-stage timing of vbm_analysis_batch: HIP events are recorded between the pipeline's kernels,
  * on the stream each kernel is launched on, for the next `max_calls` calls; profile_end waits for
  * the device and returns the summed milliseconds per stage over all launches

@@ -325,10 +325,12 @@ int orc_analysis_wrote(orc_stream *v, int vals);
 int orc_analysis_blockout(orc_stream *v, orc_block *vb); /* 1 = block ready */
 int orc_analysis(orc_stream *v, orc_block *vb);          /* vorbis_analysis + VBR bitrate hand-off */
 const unsigned char *orc_block_packet(const orc_block *vb, long *bytes);
+void orc_block_info64(const orc_block *vb, int64_t *out); /* granulepos, sequence */
 
 /* survey probe signal + driver: encodes `secs` seconds of the synthetic
  * signal and writes [int32 len][bytes] records to `out_path`; returns the packet count. */
 long orc_encode_probe(const orc_setup *s, int secs, const char *out_path, double *seconds_spent);
+void orc_probe_signal(int ch, long rate, long nsamples, float *out);
 
 #ifdef __cplusplus
 }

@@ -344,6 +344,25 @@ long orc_encode_probe(const orc_setup *s, int secs, const char *out_path, double
     return npk;
 }
 
+/* the probe driver's PCM on its own: out[c * nsamples + i], nsamples a multiple of 1024 (the driver
+ * writes whole 1024-sample chunks) */
+void orc_probe_signal(int ch, long rate, long nsamples, float *out)
+{
+    long i;
+    int c;
+    probe_lcg = 12345u;
+    for (i = 0; i < nsamples; i++) {
+        double t = (double)i / rate;
+        int burst = ((i / (rate / 3)) % 4 == 3) && (i % (rate / 3)) < 200;
+        for (c = 0; c < ch; c++) {
+            float smp = 0.3f * sin(2 * M_PI * 440.0 * (c + 1) * t) + 0.2f * sin(2 * M_PI * 3000.0 * t + c) +
+                        0.05f * probe_rnd();
+            if (burst) smp += 0.6f * probe_rnd();
+            out[c * nsamples + i] = smp;
+        }
+    }
+}
+
 /* ---- accessors for the Python test harness (tests/orc.py) -------------------------------- */
 void orc_stream_set_capture(orc_stream *v, int on) { v->capture = on; }
 
@@ -351,6 +370,11 @@ void orc_block_info(const orc_block *vb, int *out)
 {
     out[0] = vb->lW; out[1] = vb->W; out[2] = vb->nW; out[3] = vb->blocktype; out[4] = vb->pcmend;
     out[5] = vb->cap_block_mode; out[6] = vb->eofflag;
+}
+
+void orc_block_info64(const orc_block *vb, int64_t *out)
+{
+    out[0] = vb->granulepos; out[1] = vb->sequence;
 }
 
 const void *orc_block_cap(const orc_block *vb, const char *name, int ch)

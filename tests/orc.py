@@ -132,6 +132,7 @@ class Stream:
         lib.orc_block_packet.restype = C.POINTER(C.c_ubyte)
         lib.orc_block_packet.argtypes = [C.c_void_p, C.POINTER(C.c_long)]
         lib.orc_block_info.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        lib.orc_block_info64.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         lib.orc_block_cap.restype = C.c_void_p
         lib.orc_block_cap.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
         lib.orc_stream_set_capture.argtypes = [C.c_void_p, C.c_int]
@@ -152,6 +153,10 @@ class Stream:
             C.memmove(bufs[c], pcm[c].ctypes.data, n * 4)
         self.lib.orc_analysis_wrote(self.v, n)
 
+    def finish(self):
+        """vorbis_analysis_wrote(vd, 0): end of stream"""
+        self.lib.orc_analysis_wrote(self.v, 0)
+
     def _arr(self, name, c, count, dtype):
         p = self.lib.orc_block_cap(self.vb, name.encode(), c)
         buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(p)
@@ -171,7 +176,10 @@ class Stream:
             nb = C.c_long()
             pk = self.lib.orc_block_packet(self.vb, C.byref(nb))
             d = {"lW": info[0], "W": info[1], "nW": info[2], "blocktype": info[3], "N": N,
-                 "block_mode": info[5], "pcm": pcm, "packet": bytes(pk[:nb.value])}
+                 "block_mode": info[5], "eos": info[6], "pcm": pcm, "packet": bytes(pk[:nb.value])}
+            i64 = (C.c_int64 * 2)()
+            self.lib.orc_block_info64(self.vb, i64)
+            d["granulepos"], d["sequence"] = int(i64[0]), int(i64[1])
             for name in ("mdct_raw", "mdct", "logfft", "logmdct", "noise", "tone", "logmask", "epeak"):
                 d[name] = np.stack([self._arr(name, c, n, np.float32) for c in range(self.ch)])
             for name in ("ilogmask", "residue"):
@@ -188,30 +196,3 @@ class Stream:
         self.lib.orc_block_free(self.vb)
 
 
-def probe_signal(ch, rate, nsamples, seed=12345, amp=1.0, f0=440.0):
-    """The survey probe signal with a per-stream seed / pitch."""
-    lcg = np.uint32(seed)
-    out = np.empty((ch, nsamples), np.float32)
-    t = np.arange(nsamples, dtype=np.float64) / rate
-    pos = np.arange(nsamples)
-    burst = ((pos // (rate // 3)) % 4 == 3) & ((pos % (rate // 3)) < 200)
-    # LCG draws: per sample, per channel: one noise draw, plus one more when in a burst
-    draws_per = ch * (1 + burst.astype(np.int64))
-    total = int(draws_per.sum())
-    x = np.empty(total, np.uint32)
-    s = int(lcg)
-    for i in range(total):
-        s = (s * 1664525 + 1013904223) & 0xffffffff
-        x[i] = s
-    r = (((x >> 8) & 0xffff).astype(np.float32) / np.float32(32768.0)) - np.float32(1.0)
-    k = 0
-    starts = np.concatenate([[0], np.cumsum(draws_per)[:-1]])
-    for c in range(ch):
-        base = 0.3 * np.sin(2 * np.pi * f0 * (c + 1) * t) + 0.2 * np.sin(2 * np.pi * 3000.0 * t + c)
-        step = 1 + burst.astype(np.int64)
-        idx = starts + c * step
-        smp = (np.float32(0.3) * 0 + base) + (np.float32(0.05) * r[idx]).astype(np.float64)
-        smp = smp.astype(np.float32)
-        smp = np.where(burst, (smp.astype(np.float64) * 0 + smp + (np.float32(0.6) * r[idx + 1])).astype(np.float32), smp)
-        out[c] = smp * np.float32(amp)
-    return out

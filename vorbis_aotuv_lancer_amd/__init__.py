@@ -10,7 +10,7 @@ from ._lib import lib, LIB_PATH, VbmError, check  # noqa: F401
 from .tables import window_table  # noqa: F401
 from .mdct import MdctLookup, mdct_forward, window_mdct, window_fft_log  # noqa: F401
 
-from .encoder import Setup, Encoder  # noqa: F401,E402
+from .encoder import Setup, Encoder, FrontEnd, PacketInfo  # noqa: F401,E402
 
-__all__ = ["Setup", "Encoder", "lib", "LIB_PATH", "VbmError", "check", "window_table",
+__all__ = ["Setup", "Encoder", "FrontEnd", "PacketInfo", "lib", "LIB_PATH", "VbmError", "check", "window_table",
            "MdctLookup", "mdct_forward", "window_mdct", "window_fft_log"]

@@ -51,6 +51,12 @@ SIGNATURES = {
     "vbm_encoder_profile_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "vbm_encoder_set_sub_batches": (C.c_int, [C.c_void_p, C.c_int]),
     "vbm_encoder_sub_batches": (C.c_int, [C.c_void_p]),
+    "vbm_frontend_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p]),
+    "vbm_frontend_destroy": (None, [C.c_void_p]),
+    "vbm_frontend_reset": (C.c_int, [C.c_void_p]),
+    "vbm_frontend_write": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "vbm_frontend_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "vbm_frontend_encode_round": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]),
     "vbm_encoder_stage_count": (C.c_int, []),
     "vbm_encoder_stage_name": (C.c_char_p, [C.c_int]),
     "vbm_host_mdct_trig": (C.c_int, [C.c_int, C.c_void_p]),

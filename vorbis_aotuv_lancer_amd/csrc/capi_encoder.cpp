@@ -277,6 +277,10 @@ extern "C" int vbm_encoder_set_sub_batches(vbm_encoder *e, int n)
 
 extern "C" int vbm_encoder_sub_batches(const vbm_encoder *e) { return e ? e->nsplit : VBM_EINVAL; }
 
+// internal accessors for the stream front end (capi_frontend.cpp)
+vbm_setup_host *vbm_encoder_setup_host(vbm_encoder *e) { return e->H; }
+int vbm_encoder_streams(const vbm_encoder *e) { return e->S; }
+
 extern "C" int vbm_encoder_max_packet_bytes(const vbm_encoder *e) { return e ? e->max_packet_bytes : VBM_EINVAL; }
 
 extern "C" int vbm_encoder_reset(vbm_encoder *e)

@@ -1,0 +1,308 @@
+// Stream front end object (include/vorbis_mi355x.h, "stream front end"): PCM in, packets out, for
+// all streams of one vbm_encoder.  Batched equivalent of the application loop
+//     vorbis_analysis_buffer / vorbis_analysis_wrote;  while (vorbis_analysis_blockout(vd, vb) == 1)
+//     { vorbis_analysis(vb, NULL); vorbis_bitrate_addblock(vb); vorbis_bitrate_flushpacket(vd, &op) }
+// (reference examples/encoder_example.c:190-235, lib/block.c:405-812, lib/envelope.c).
+// Kernels: frontend_kernels.hip; the per-block path behind them is vbm_analysis_batch.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "vorbis_mi355x.h"
+#include "setup_host.h"
+#include "frontend.h"
+#include "frontend_kernels.h"
+#include "mdct_kernel.h"
+#include "vbm_internal.h"
+
+vbm_setup_host *vbm_encoder_setup_host(vbm_encoder *e);
+int vbm_encoder_streams(const vbm_encoder *e);
+
+struct vbm_frontend {
+    vbm_encoder *enc;
+    vbm_setup_host *H;
+    const vbm_setup *hs;
+    int S, ch;
+    vbm_fe_state f;                       // device pointers
+    std::vector<void *> allocs;
+    vbm_fe_decision *d_dec = nullptr, *h_dec = nullptr;   // [S] device / pinned host
+    int *d_ids = nullptr, *d_begin = nullptr;             // [S] per-round lists, grouped by block type
+    int *h_ids = nullptr, *h_begin = nullptr;             // pinned
+    uint8_t *h_flags = nullptr;
+    float *d_blocks = nullptr;            // [S][ch][blocksizes[1]] block-major batches of one round
+    // host mirrors (bounds checking and skipping rounds that cannot produce a block)
+    std::vector<int> pcm_current, W, started, ended;
+    bool dirty = false;                   // samples arrived since the envelope was last evaluated
+    int pending_steps = 0;                // upper bound of search steps not yet evaluated
+};
+
+template <typename T>
+static int fe_alloc(vbm_frontend *fe, T **p, size_t count)
+{
+    hipError_t err = hipMalloc((void **)p, count * sizeof(T) + 256);
+    if (err != hipSuccess) return vbm_set_hip_error(err, "hipMalloc(front end)");
+    fe->allocs.push_back(*p);
+    err = hipMemset(*p, 0, count * sizeof(T) + 256);
+    if (err != hipSuccess) return vbm_set_hip_error(err, "hipMemset");
+    return 0;
+}
+
+extern "C" void vbm_frontend_destroy(vbm_frontend *fe)
+{
+    if (!fe) return;
+    for (void *p : fe->allocs) (void)hipFree(p);
+    if (fe->h_dec) (void)hipHostFree(fe->h_dec);
+    if (fe->h_ids) (void)hipHostFree(fe->h_ids);
+    if (fe->h_begin) (void)hipHostFree(fe->h_begin);
+    if (fe->h_flags) (void)hipHostFree(fe->h_flags);
+    delete fe;
+}
+
+extern "C" int vbm_frontend_create(vbm_frontend **out, vbm_encoder *enc)
+{
+    if (!out || !enc) return VBM_EINVAL;
+    *out = nullptr;
+    vbm_frontend *fe = new vbm_frontend();
+    fe->enc = enc;
+    fe->H = vbm_encoder_setup_host(enc);
+    fe->hs = vbm_setup_host_view(fe->H);
+    const vbm_setup *s = fe->hs;
+    const int S = fe->S = vbm_encoder_streams(enc), ch = fe->ch = s->channels;
+    const int bs1 = s->blocksizes[1];
+    vbm_fe_state &f = fe->f;
+    memset(&f, 0, sizeof(f));
+    f.S = S;
+    f.ch = ch;
+    // room for the carried window (< 2 long blocks), one write of up to 2 long blocks and the three
+    // long blocks of end-of-stream padding (lib/block.c:527-529)
+    f.cap = (long)bs1 * 8;
+    f.plane = (long)S * ch * f.cap;
+    f.marks = (int)(f.cap / 64) + 8;
+    int rc = 0;
+#define A(field, type, count) do { type *p_; rc = fe_alloc<type>(fe, &p_, (count)); if (rc) { vbm_frontend_destroy(fe); return rc; } field = p_; } while (0)
+    const size_t SC = (size_t)S * ch;
+    A(f.pcm, float, (size_t)2 * f.plane);
+    A(f.parity, int, S);
+    A(f.pcm_current, int, S); A(f.centerW, int, S); A(f.lW, int, S); A(f.W, int, S); A(f.nW, int, S);
+    A(f.eofflag, int, S); A(f.preextrapolate, int, S);
+    A(f.granulepos, long long, S); A(f.sequence, long long, S);
+    A(f.ve_current, int, S); A(f.ve_cursor, int, S); A(f.ve_curmark, int, S); A(f.ve_stretch, int, S);
+    A(f.ve_mark, int, (size_t)f.marks * S);
+    A(f.ve_ampbuf, float, (size_t)VBM_VE_BANDS * VBM_VE_AMP * SC);
+    A(f.ve_ampptr, int, (size_t)VBM_VE_BANDS * SC);
+    A(f.ve_nearDC, float, (size_t)VBM_VE_NEARDC * SC);
+    A(f.ve_nearacc, float, (size_t)2 * SC);
+    A(f.ve_nearptr, int, SC);
+    A(f.ve_first, int, S); A(f.ve_last, int, S);
+    A(f.ve_spec, float, SC * VBM_FE_CHUNK * 64);
+    A(fe->d_dec, vbm_fe_decision, S);
+    A(fe->d_ids, int, S); A(fe->d_begin, int, S);
+    A(fe->d_blocks, float, SC * bs1);
+#undef A
+    if (hipHostMalloc((void **)&fe->h_dec, S * sizeof(vbm_fe_decision), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void **)&fe->h_ids, S * sizeof(int), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void **)&fe->h_begin, S * sizeof(int), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void **)&fe->h_flags, S, hipHostMallocDefault) != hipSuccess) {
+        vbm_frontend_destroy(fe);
+        g_vbm_err = "hipHostMalloc(front end) failed";
+        return VBM_EHIP;
+    }
+    fe->pcm_current.assign(S, 0);
+    fe->W.assign(S, 0);
+    fe->started.assign(S, 0);
+    fe->ended.assign(S, 0);
+    rc = vbm_frontend_reset(fe);
+    if (rc) { vbm_frontend_destroy(fe); return rc; }
+    *out = fe;
+    return VBM_OK;
+}
+
+// vorbis_analysis_init state (lib/block.c:306-344, _ve_envelope_init lib/envelope.c:42-87)
+extern "C" int vbm_frontend_reset(vbm_frontend *fe)
+{
+    if (!fe) return VBM_EINVAL;
+    const vbm_fe_state &f = fe->f;
+    const int S = fe->S, bs1 = fe->hs->blocksizes[1];
+    const size_t SC = (size_t)S * fe->ch;
+    hipError_t err = hipSuccess;
+    auto zero = [&](void *p, size_t bytes) { if (err == hipSuccess) err = hipMemset(p, 0, bytes); };
+    zero(f.pcm, (size_t)2 * f.plane * sizeof(float));
+    zero(f.parity, S * sizeof(int));
+    zero(f.lW, S * sizeof(int)); zero(f.W, S * sizeof(int)); zero(f.nW, S * sizeof(int));
+    zero(f.eofflag, S * sizeof(int)); zero(f.preextrapolate, S * sizeof(int));
+    zero(f.granulepos, S * sizeof(long long));
+    zero(f.ve_current, S * sizeof(int)); zero(f.ve_stretch, S * sizeof(int));
+    zero(f.ve_mark, (size_t)f.marks * S * sizeof(int));
+    zero(f.ve_ampbuf, (size_t)VBM_VE_BANDS * VBM_VE_AMP * SC * sizeof(float));
+    zero(f.ve_ampptr, (size_t)VBM_VE_BANDS * SC * sizeof(int));
+    zero(f.ve_nearDC, (size_t)VBM_VE_NEARDC * SC * sizeof(float));
+    zero(f.ve_nearacc, 2 * SC * sizeof(float));
+    zero(f.ve_nearptr, SC * sizeof(int));
+    if (err != hipSuccess) return vbm_set_hip_error(err, "hipMemset(front end)");
+    std::vector<int> half(S, bs1 / 2), minus1(S, -1);
+    std::vector<long long> seq(S, 3);   // the three header packets come first (lib/block.c:337)
+    if ((err = hipMemcpy(f.pcm_current, half.data(), S * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess ||
+        (err = hipMemcpy(f.centerW, half.data(), S * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess ||
+        (err = hipMemcpy(f.ve_cursor, half.data(), S * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess ||
+        (err = hipMemcpy(f.ve_curmark, minus1.data(), S * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess ||
+        (err = hipMemcpy(f.sequence, seq.data(), S * sizeof(long long), hipMemcpyHostToDevice)) != hipSuccess)
+        return vbm_set_hip_error(err, "hipMemcpy(front end init)");
+    fe->pcm_current.assign(S, bs1 / 2);
+    fe->W.assign(S, 0);
+    fe->started.assign(S, 0);
+    fe->ended.assign(S, 0);
+    fe->dirty = false;
+    fe->pending_steps = 0;
+    return VBM_OK;
+}
+
+extern "C" int vbm_frontend_write(vbm_frontend *fe, const float *d_pcm, int vals, void *stream)
+{
+    if (!fe || !d_pcm || vals <= 0) return VBM_EINVAL;
+    const vbm_setup *s = fe->hs;
+    const int bs1 = s->blocksizes[1];
+    if (vals > 2 * bs1) return VBM_EINVAL;
+    for (int i = 0; i < fe->S; i++) {
+        if (fe->ended[i]) { g_vbm_err = "vbm_frontend_write after vbm_frontend_finish"; return VBM_EINVAL; }
+        if (fe->pcm_current[i] + vals > fe->f.cap - 3 * bs1) {   // OV_EINVAL of lib/block.c:540-541
+            g_vbm_err = "PCM buffer full: drain blocks with vbm_frontend_encode_round before writing more";
+            return VBM_EINVAL;
+        }
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (vbm_fe_launch_append(&fe->f, d_pcm, vals, s->pre_amplitude, st)) return VBM_EHIP;
+    bool cross = false;
+    for (int i = 0; i < fe->S; i++) {
+        fe->pcm_current[i] += vals;
+        // vorbis_analysis_wrote: first time more than one long block follows centerW (lib/block.c:547-550)
+        if (!fe->started[i] && fe->pcm_current[i] - bs1 / 2 > bs1) { fe->started[i] = 1; cross = true; }
+    }
+    if (cross && vbm_fe_launch_extrapolate(&fe->f, nullptr, 0, 0, bs1, st)) return VBM_EHIP;
+    fe->dirty = true;
+    fe->pending_steps += vals / 64 + 1;
+    if (cross) fe->pending_steps += (bs1 / 2 + bs1) / 64;   // the first search starts at step 0
+    return VBM_OK;
+}
+
+extern "C" int vbm_frontend_finish(vbm_frontend *fe, const int *stream_ids, int n, void *stream)
+{
+    if (!fe || n < 0 || (n && !stream_ids)) return VBM_EINVAL;
+    if (n == 0) return VBM_OK;
+    const int bs1 = fe->hs->blocksizes[1];
+    for (int i = 0; i < n; i++) {
+        int s = stream_ids[i];
+        if (s < 0 || s >= fe->S || fe->ended[s]) return VBM_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    (void)hipStreamSynchronize(st);   // h_ids is reused by the rounds
+    memcpy(fe->h_ids, stream_ids, n * sizeof(int));
+    hipError_t err = hipMemcpyAsync(fe->d_ids, fe->h_ids, n * sizeof(int), hipMemcpyHostToDevice, st);
+    if (err != hipSuccess) return vbm_set_hip_error(err, "hipMemcpyAsync(finish ids)");
+    if (vbm_fe_launch_extrapolate(&fe->f, fe->d_ids, n, 1, bs1, st)) return VBM_EHIP;
+    (void)hipStreamSynchronize(st);
+    for (int i = 0; i < n; i++) {
+        int s = stream_ids[i];
+        fe->ended[s] = 1;
+        fe->started[s] = 1;
+        fe->pcm_current[s] += 3 * bs1;
+    }
+    fe->dirty = true;
+    fe->pending_steps += 3 * bs1 / 64 + (bs1 / 2 + bs1) / 64 + 1;
+    return VBM_OK;
+}
+
+extern "C" int vbm_frontend_encode_round(vbm_frontend *fe, uint8_t *d_packets, int *d_packet_bytes,
+                                         vbm_packet_info *info, int *nblocks, void *stream)
+{
+    if (!fe || !nblocks || !info) return VBM_EINVAL;
+    *nblocks = 0;
+    const vbm_setup *s = fe->hs;
+    const vbm_setup *ds = vbm_setup_device(fe->H);
+    const int S = fe->S, ch = fe->ch;
+    const int bs0 = s->blocksizes[0], bs1 = s->blocksizes[1];
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t err;
+
+    // can any stream have a block?  (host mirrors: the smallest possible block bound is a short
+    // next window, lib/block.c:593-600)
+    bool maybe = false;
+    for (int i = 0; i < S && !maybe; i++) {
+        if (!fe->started[i]) continue;
+        const int bsW = fe->W[i] ? bs1 : bs0;
+        if (fe->pcm_current[i] >= bs1 / 2 + bsW / 4 + bs0 / 4 + bs0 / 2) maybe = true;
+    }
+    if (!maybe) return VBM_OK;
+
+    // evaluate the envelope over everything written since the last round (_ve_envelope_search, first part)
+    if (fe->dirty) {
+        if (vbm_fe_launch_ve_range(&fe->f, st)) return VBM_EHIP;
+        vbm_ve_gather g;
+        g.pcm = fe->f.pcm;
+        g.first = fe->f.ve_first; g.last = fe->f.ve_last; g.parity = fe->f.parity;
+        g.ch = ch; g.steps = VBM_FE_CHUNK; g.cap = fe->f.cap; g.plane = fe->f.plane;
+        for (int t0 = 0; t0 < fe->pending_steps; t0 += VBM_FE_CHUNK) {
+            g.t0 = t0;
+            if (vbm_launch_ve_mdct(&g, fe->f.ve_spec, vbm_setup_device_ptrs(fe->H)->ve.mdct_trig,
+                                   vbm_setup_device_ptrs(fe->H)->ve.mdct_win, (long)S * ch * VBM_FE_CHUNK, st))
+                return VBM_EHIP;
+            if (vbm_fe_launch_ve_filter(&fe->f, ds, t0, st)) return VBM_EHIP;
+        }
+        fe->dirty = false;
+        fe->pending_steps = 0;
+    }
+
+    if (vbm_fe_launch_decide(&fe->f, ds, fe->d_dec, st)) return VBM_EHIP;
+    if ((err = hipMemcpyAsync(fe->h_dec, fe->d_dec, S * sizeof(vbm_fe_decision), hipMemcpyDeviceToHost, st)) != hipSuccess)
+        return vbm_set_hip_error(err, "hipMemcpyAsync(decisions)");
+    if ((err = hipStreamSynchronize(st)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamSynchronize");
+
+    // group the ready blocks by block type
+    int count[4] = {0, 0, 0, 0}, offset[4];
+    for (int i = 0; i < S; i++)
+        if (fe->h_dec[i].ready) count[fe->h_dec[i].block_mode & 3]++;
+    offset[0] = 0;
+    for (int m = 1; m < 4; m++) offset[m] = offset[m - 1] + count[m - 1];
+    const int total = offset[3] + count[3];
+    if (total == 0) return VBM_OK;
+    {
+        int fill[4] = {offset[0], offset[1], offset[2], offset[3]};
+        for (int i = 0; i < S; i++) {
+            const vbm_fe_decision &d = fe->h_dec[i];
+            if (!d.ready) continue;
+            const int k = fill[d.block_mode & 3]++;
+            fe->h_ids[k] = i;
+            fe->h_begin[k] = d.beginW;
+            fe->h_flags[k] = (uint8_t)(d.lW | (d.nW << 1));
+            vbm_packet_info &pi = info[k];
+            pi.stream = i; pi.block_mode = d.block_mode; pi.lW = d.lW; pi.W = d.W; pi.nW = d.nW; pi.eos = d.eos;
+            pi.granulepos = d.granulepos; pi.packetno = d.sequence;
+            // host mirrors
+            if (d.movement > 0) {
+                fe->pcm_current[i] -= d.movement;
+                fe->W[i] = d.nW;
+            }
+            if (d.eos) fe->started[i] = 0;   // stream over: no further blocks
+        }
+    }
+    if ((err = hipMemcpyAsync(fe->d_ids, fe->h_ids, total * sizeof(int), hipMemcpyHostToDevice, st)) != hipSuccess ||
+        (err = hipMemcpyAsync(fe->d_begin, fe->h_begin, total * sizeof(int), hipMemcpyHostToDevice, st)) != hipSuccess)
+        return vbm_set_hip_error(err, "hipMemcpyAsync(round lists)");
+
+    const int maxb = vbm_encoder_max_packet_bytes(fe->enc);
+    for (int m = 0; m < 4; m++) {
+        if (!count[m]) continue;
+        const int N = (m >> 1) ? bs1 : bs0;
+        float *blocks = fe->d_blocks + (size_t)offset[m] * ch * bs1;
+        if (vbm_fe_launch_gather(&fe->f, fe->d_ids + offset[m], fe->d_begin + offset[m], count[m], N, blocks, st))
+            return VBM_EHIP;
+        int rc = vbm_analysis_batch(fe->enc, m, count[m], fe->h_ids + offset[m], fe->h_flags + offset[m], blocks,
+                                    d_packets ? d_packets + (size_t)offset[m] * maxb : nullptr,
+                                    d_packet_bytes ? d_packet_bytes + offset[m] : nullptr, stream);
+        if (rc) return rc;
+    }
+    if (vbm_fe_launch_shift(&fe->f, fe->d_dec, st)) return VBM_EHIP;
+    *nblocks = total;
+    return VBM_OK;
+}

@@ -1,0 +1,47 @@
+// Device-resident stream front end: the part of libvorbis that sits between the application's PCM
+// and vorbis_analysis() — vorbis_analysis_buffer / _wrote / _blockout (reference lib/block.c:405-812)
+// and the envelope detector that drives block switching (lib/envelope.c) — for S streams at once.
+//
+// Every stream keeps the reference's own coordinates (centerW, pcm_current, ve_current, ... are the
+// same numbers the reference would hold), so the decisions can be checked value by value.  The
+// PCM of a channel lives in one of two buffers of `cap` floats; where the reference memmove()s the
+// buffer down after a block (lib/block.c:757-759), the shift kernel copies into the other buffer
+// and flips the stream's parity.
+#pragma once
+#include <stdint.h>
+#include "setup.h"
+
+#define VBM_FE_CHUNK 32          /* search steps evaluated per launch of the envelope kernels */
+
+struct vbm_fe_state {
+    int S, ch;
+    long cap;                    // floats per channel buffer
+    long plane;                  // S*ch*cap
+    int marks;                   // entries of the per-stream mark ring (cap/64 + 8)
+    float *pcm;                  // [2][S*ch][cap]
+    int *parity;                 // [S]
+    // vorbis_dsp_state (lib/block.c:173-344 initial values)
+    int *pcm_current, *centerW, *lW, *W, *nW, *eofflag, *preextrapolate;   // [S]
+    long long *granulepos, *sequence;                                      // [S]
+    // envelope_lookup (lib/envelope.h:56-76); SoA with the stream / channel index innermost
+    int *ve_current, *ve_cursor, *ve_curmark, *ve_stretch;                 // [S]
+    int *ve_mark;                // [marks][S]
+    float *ve_ampbuf;            // [VE_BANDS][VE_AMP][S*ch]
+    int *ve_ampptr;              // [VE_BANDS][S*ch]
+    float *ve_nearDC;            // [VE_NEARDC][S*ch]
+    float *ve_nearacc;           // [2][S*ch]   nearDC_acc, nearDC_partialacc
+    int *ve_nearptr;             // [S*ch]
+    int *ve_first, *ve_last;     // [S] search steps [first, last) still to evaluate
+    float *ve_spec;              // [S*ch][VBM_FE_CHUNK][64] spectra of the 128-point search MDCTs
+};
+
+// one per stream and round (host readable)
+struct vbm_fe_decision {
+    int ready;                   // vorbis_analysis_blockout returned 1
+    int lW, W, nW;
+    int block_mode;              // blocktype | W << 1   (lib/mapping0.c:768-775)
+    int eos;                     // vb->eofflag
+    int beginW;                  // first sample of the block in the (pre-shift) buffer
+    int movement;                // samples the buffer moves down after this block
+    long long granulepos, sequence;
+};

@@ -1,0 +1,566 @@
+// Stream front end kernels for gfx950 (frontend.h): PCM intake, LPC extrapolation of stream start
+// and end, the envelope detector and the block carve-out decision, for S streams per launch.
+//
+//   k_fe_append / k_fe_commit       vorbis_analysis_buffer + vorbis_analysis_wrote(vals > 0)
+//                                   (reference lib/block.c:405-436, :511-553): pre_amplitude, append
+//   k_fe_extrapolate                _preextrapolate_helper (lib/block.c:438-484) and the end-of-stream
+//                                   padding of vorbis_analysis_wrote(0) (:520-552), with
+//                                   vorbis_lpc_from_data / vorbis_lpc_predict (lib/lpc.c:60-159).
+//                                   One lane per channel: Levinson-Durbin in double, in source order.
+//   k_fe_ve_range                   which search steps [first, last) _ve_envelope_search still has to
+//                                   evaluate (lib/envelope.c:573-577)
+//   (128-point search MDCTs: mdct_kernel.hip, vbm_launch_ve_mdct)
+//   k_fe_ve_filter                  _ve_amp after its MDCT (lib/envelope.c:127-562, scalar branch) and
+//                                   the mark bookkeeping of _ve_envelope_search (:590-625); one lane per
+//                                   stream, because ve->stretch couples the channels step by step
+//   k_fe_decide                     the cursor walk of _ve_envelope_search (:631-678), _ve_envelope_mark
+//                                   (:683-707), vorbis_analysis_blockout (lib/block.c:557-812) without
+//                                   its copies, _ve_envelope_shift (:709-728)
+//   k_fe_gather                     the block copy of vorbis_analysis_blockout (lib/block.c:653-698)
+//                                   into block-major batches for vbm_analysis_batch
+//   k_fe_shift                      the memmove of lib/block.c:757-759 as a copy into the other buffer
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "batch.h"
+#include "frontend.h"
+#include "frontend_kernels.h"
+
+namespace {
+
+__device__ __forceinline__ float *chan_buf(const vbm_fe_state &f, int s, int c)
+{
+    return f.pcm + (long)f.parity[s] * f.plane + ((long)s * f.ch + c) * f.cap;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void k_fe_append(vbm_fe_state f, const float *__restrict__ src, int vals, float pre_amplitude)
+{
+    const int c = blockIdx.x;                       // channel index over S*ch
+    const int s = c / f.ch;
+    float *dst = f.pcm + (long)f.parity[s] * f.plane + (long)c * f.cap + f.pcm_current[s];
+    const float *in = src + (long)c * vals;
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < vals; i += gridDim.y * blockDim.x)
+        dst[i] = in[i] * pre_amplitude;             // lib/block.c:514-518
+}
+
+__global__ void k_fe_commit(vbm_fe_state f, int vals)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < f.S) f.pcm_current[s] += vals;
+}
+
+// ---------------------------------------------------------------------------------------------
+// vorbis_lpc_from_data (lib/lpc.c:60-130).  data(i) is an accessor; M = order
+template <int M, typename Acc>
+__device__ void lpc_from_data(Acc data, float *lpci, int n)
+{
+    double aut[M + 1], lpc[M];
+    double error, epsilon;
+    int i, j;
+
+    j = M + 1;
+    while (j--) {
+        double d = 0;
+        for (i = j; i < n; i++) d += (double)data(i) * (double)data(i - j);
+        aut[j] = d;
+    }
+
+    error = aut[0] * (1. + 1e-10);
+    epsilon = 1e-9 * aut[0] + 1e-10;
+
+    for (i = 0; i < M; i++) {
+        double r = -aut[i + 1];
+        if (error < epsilon) {
+            for (j = i; j < M; j++) lpc[j] = 0.;
+            break;
+        }
+        for (j = 0; j < i; j++) r -= lpc[j] * aut[i - j];
+        r /= error;
+
+        lpc[i] = r;
+        for (j = 0; j < i / 2; j++) {
+            double tmp = lpc[j];
+            lpc[j] += r * lpc[i - 1 - j];
+            lpc[i - 1 - j] += r * tmp;
+        }
+        if (i & 1) lpc[j] += lpc[j] * r;
+
+        error *= 1. - r * r;
+    }
+    {
+        double g = .99;
+        double damp = g;
+        for (j = 0; j < M; j++) {
+            lpc[j] *= damp;
+            damp *= g;
+        }
+    }
+    for (j = 0; j < M; j++) lpci[j] = (float)lpc[j];
+}
+
+// vorbis_lpc_predict (lib/lpc.c:132-159): prime(i) = the M samples before the first predicted one,
+// out(i, y) stores sample i.  The M-sample history slides through registers.
+template <int M, typename Prime, typename Out>
+__device__ void lpc_predict(const float *coeff, Prime prime, Out out, long n)
+{
+    float w[M];
+#pragma unroll
+    for (int i = 0; i < M; i++) w[i] = prime(i);
+    for (long i = 0; i < n; i++) {
+        float y = 0;
+#pragma unroll
+        for (int j = 0; j < M; j++) y -= w[j] * coeff[M - 1 - j];
+#pragma unroll
+        for (int j = 0; j < M - 1; j++) w[j] = w[j + 1];
+        w[M - 1] = y;
+        out(i, y);
+    }
+}
+
+// mode 0: start-of-stream pre-extrapolation for every stream that just crossed the threshold of
+//         vorbis_analysis_wrote (lib/block.c:547-550); ids == nullptr, lanes cover all channels.
+// mode 1: vorbis_analysis_wrote(v, 0) for the listed streams (lib/block.c:520-545).
+__global__ void k_fe_extrapolate(vbm_fe_state f, const int *__restrict__ ids, int nids, int mode, int long_n)
+{
+    const int lane = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nch = (mode == 0 ? f.S : nids) * f.ch;
+    if (lane >= nch) return;
+    const int s = mode == 0 ? lane / f.ch : ids[lane / f.ch];
+    const int c = lane % f.ch;
+    float *pcm = chan_buf(f, s, c);
+    const int pc = f.pcm_current[s], centerW = f.centerW[s];
+
+    if (!f.preextrapolate[s] && (mode == 1 || pc - centerW > long_n)) {
+        // _preextrapolate_helper: work[j] = pcm[pc-1-j]; LPC on the real data (reversed), then
+        // predict the centerW samples in front of it
+        const int order = 16;
+        if (pc - centerW > order * 2) {
+            float lpc[16];
+            const int n = pc - centerW;
+            lpc_from_data<16>([&](int i) { return pcm[pc - 1 - i]; }, lpc, n);
+            lpc_predict<16>(lpc, [&](int i) { return pcm[pc - 1 - (n - order + i)]; },
+                            [&](long i, float y) { pcm[pc - 1 - (n + i)] = y; }, centerW);
+        }
+    }
+    if (mode == 1) {
+        const int order = 32;
+        const int eof = pc, newpc = pc + long_n * 3;
+        if (eof > order * 2) {
+            float lpc[32];
+            int n = eof;
+            if (n > long_n) n = long_n;
+            const float *d = pcm + eof - n;
+            lpc_from_data<32>([&](int i) { return d[i]; }, lpc, n);
+            lpc_predict<32>(lpc, [&](int i) { return pcm[eof - order + i]; },
+                            [&](long i, float y) { pcm[eof + i] = y; }, newpc - eof);
+        } else {
+            for (int i = eof; i < newpc; i++) pcm[i] = 0.f;
+        }
+    }
+}
+
+// state part of the two paths above, after every channel has been extrapolated
+__global__ void k_fe_extrapolate_commit(vbm_fe_state f, const int *__restrict__ ids, int nids, int mode, int long_n)
+{
+    const int lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= (mode == 0 ? f.S : nids)) return;
+    const int s = mode == 0 ? lane : ids[lane];
+    if (mode == 0) {
+        if (!f.preextrapolate[s] && f.pcm_current[s] - f.centerW[s] > long_n) f.preextrapolate[s] = 1;
+    } else {
+        f.preextrapolate[s] = 1;
+        f.eofflag[s] = f.pcm_current[s];
+        f.pcm_current[s] += long_n * 3;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void k_fe_ve_range(vbm_fe_state f)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= f.S) return;
+    const int searchstep = 64;
+    int first = f.ve_current[s] / searchstep;
+    int last = f.pcm_current[s] / searchstep - VBM_VE_WIN;
+    if (first < 0) first = 0;
+    // vorbis_analysis_blockout only reaches the search once the start is extrapolated and the stream
+    // has not ended (lib/block.c:564-566)
+    if (!f.preextrapolate[s] || f.eofflag[s] == -1) last = first;
+    f.ve_first[s] = first;
+    f.ve_last[s] = last;
+}
+
+// lib/scales.h:43-51
+__device__ __forceinline__ float fe_todB(float x)
+{
+    uint32_t i = __float_as_uint(x) & 0x7fffffffu;
+    return (float)((float)i * 7.17711438e-7f - 764.6161886f);
+}
+
+// steps [first + t0, min(last, first + t0 + CHUNK)) of every stream; 64 streams per wavefront
+__global__ __launch_bounds__(64) void k_fe_ve_filter(vbm_fe_state f, const vbm_setup *__restrict__ setup, int t0)
+{
+    __shared__ float s_vec[32][64];
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= f.S) return;
+    const int l = threadIdx.x;
+    const vbm_envelope *ve = &setup->ve;
+    const int SC = f.S * f.ch;
+    const int first = f.ve_first[s] + t0, last = f.ve_last[s];
+    if (first >= last) return;
+    const float minV = ve->minenergy;
+    const float stretch_penalty = ve->stretch_penalty;
+    int ve_stretch = f.ve_stretch[s];
+    const int S = f.S;
+
+    for (int t = 0; t < VBM_FE_CHUNK; t++) {
+        const int j = first + t;
+        if (j >= last) break;
+        int ret = 0;
+
+        ve_stretch++;
+        if (ve_stretch > VBM_VE_MAXSTRETCH * 2) ve_stretch = VBM_VE_MAXSTRETCH * 2;
+
+        // _ve_amp prologue (lib/envelope.c:112-119)
+        int stretch = ve_stretch / 2;
+        if (stretch < VBM_VE_MINSTRETCH) stretch = VBM_VE_MINSTRETCH;
+        float penalty = stretch_penalty - (ve_stretch / 2 - VBM_VE_MINSTRETCH);
+        if (penalty < 0.f) penalty = 0.f;
+        if (penalty > stretch_penalty) penalty = stretch_penalty;
+
+        for (int ci = 0; ci < f.ch; ci++) {
+            const int c = s * f.ch + ci;
+            const float4 *spec = reinterpret_cast<const float4 *>(f.ve_spec + ((long)c * VBM_FE_CHUNK + t) * 64);
+            float decay;
+
+            // near-DC spreading function (:127-148)
+            const float4 h0 = spec[0];
+            {
+                float temp = (float)((double)(h0.x * h0.x) + (.7 * (double)h0.y) * (double)h0.y + (.2 * (double)h0.z) * (double)h0.z);
+                int ptr = f.ve_nearptr[c];
+                float acc = f.ve_nearacc[c], pacc = f.ve_nearacc[SC + c];
+                if (ptr == 0) {
+                    decay = acc = pacc + temp;
+                    pacc = temp;
+                } else {
+                    decay = acc += temp;
+                    pacc += temp;
+                }
+                acc -= f.ve_nearDC[(long)ptr * SC + c];
+                f.ve_nearDC[(long)ptr * SC + c] = temp;
+                f.ve_nearacc[c] = acc;
+                f.ve_nearacc[SC + c] = pacc;
+
+                decay = (float)((double)decay * (1. / (VBM_VE_NEARDC + 1)));
+                ptr++;
+                if (ptr >= VBM_VE_NEARDC) ptr = 0;
+                f.ve_nearptr[c] = ptr;
+                decay = (float)((double)fe_todB(decay) * .5 - (double)15.f);
+            }
+
+            // spreading, limiting, spectrum smoothing (:151-159)
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const float4 h = spec[q];
+                float val = h.x * h.x + h.y * h.y;
+                val = fe_todB(val) * .5f;
+                if (val < decay) val = decay;
+                if (val < minV) val = minV;
+                s_vec[2 * q][l] = val;
+                decay = (float)((double)decay - 8.);
+                val = h.z * h.z + h.w * h.w;
+                val = fe_todB(val) * .5f;
+                if (val < decay) val = decay;
+                if (val < minV) val = minV;
+                s_vec[2 * q + 1][l] = val;
+                decay = (float)((double)decay - 8.);
+            }
+
+            // preecho / postecho triggering by band (:162-559 scalar)
+            for (int jb = 0; jb < VBM_VE_BANDS; jb++) {
+                float acc = 0.f;
+                const int begin = ve->band_begin[jb], end = ve->band_end[jb];
+                for (int i = 0; i < end; i++) acc += s_vec[i + begin][l] * ve->band_window[jb][i];
+                acc *= ve->band_total[jb];
+
+                float *ampbuf = f.ve_ampbuf + (long)jb * VBM_VE_AMP * SC + c;   // element k at [k*SC]
+                const int cur = f.ve_ampptr[(long)jb * SC + c];
+                float postmax, postmin, premax = -99999.f, premin = 99999.f;
+                int p = cur;
+                p--;
+                if (p < 0) p += VBM_VE_AMP;
+                {
+                    const float a = ampbuf[(long)p * SC];
+                    postmax = acc > a ? acc : a;
+                    postmin = acc < a ? acc : a;
+                }
+                for (int i = 0; i < stretch; i++) {
+                    p--;
+                    if (p < 0) p += VBM_VE_AMP;
+                    const float a = ampbuf[(long)p * SC];
+                    premax = premax > a ? premax : a;
+                    premin = premin < a ? premin : a;
+                }
+                const float valmin = postmin - premin;
+                const float valmax = postmax - premax;
+
+                ampbuf[(long)cur * SC] = acc;
+                int np = cur + 1;
+                if (np >= VBM_VE_AMP) np = 0;
+                f.ve_ampptr[(long)jb * SC + c] = np;
+
+                if (valmax > ve->preecho_thresh[jb] + penalty) ret |= 1 | 4;
+                if (valmin < ve->postecho_thresh[jb] - penalty) ret |= 2;
+            }
+        }
+
+        // mark bookkeeping of _ve_envelope_search (lib/envelope.c:611-624)
+        f.ve_mark[(long)(j + VBM_VE_POST) * S + s] = 0;
+        if (ret & 1) {
+            f.ve_mark[(long)j * S + s] = 1;
+            f.ve_mark[(long)(j + 1) * S + s] = 1;
+        }
+        if (ret & 2) {
+            f.ve_mark[(long)j * S + s] = 1;
+            if (j > 0) f.ve_mark[(long)(j - 1) * S + s] = 1;
+        }
+        if (ret & 4) ve_stretch = -1;
+    }
+    f.ve_stretch[s] = ve_stretch;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void k_fe_decide(vbm_fe_state f, const vbm_setup *__restrict__ setup, vbm_fe_decision *__restrict__ out)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= f.S) return;
+    const int S = f.S;
+    const int searchstep = 64;
+    const int bs0 = setup->blocksizes[0], bs1 = setup->blocksizes[1];
+    vbm_fe_decision d;
+    d.ready = 0; d.lW = d.W = d.nW = 0; d.block_mode = 0; d.eos = 0; d.beginW = 0; d.movement = 0;
+    d.granulepos = 0; d.sequence = 0;
+
+    int W = f.W[s], lW = f.lW[s], nW = f.nW[s];
+    int centerW = f.centerW[s], pcm_current = f.pcm_current[s], eofflag = f.eofflag[s];
+    const int bsW = W ? bs1 : bs0;
+    const int beginW = centerW - bsW / 2;
+
+    if (!f.preextrapolate[s] || eofflag == -1) {
+        out[s] = d;
+        return;
+    }
+
+    // _ve_envelope_search, after its evaluation loop (lib/envelope.c:627-680)
+    int bp = -1;
+    {
+        // ve->current = last * searchstep with last recomputed from the present pcm_current; every step
+        // below it has been evaluated by k_fe_ve_filter before this kernel runs
+        const int ve_current = (pcm_current / searchstep - VBM_VE_WIN) * searchstep;
+        f.ve_current[s] = ve_current;
+        const int testW = centerW + bsW / 4 + bs1 / 2 + bs0 / 4;
+        int j = f.ve_cursor[s];
+        int cursor = j, curmark = f.ve_curmark[s];
+        while (j < ve_current - searchstep) {
+            if (j >= testW) { bp = 1; break; }
+            cursor = j;
+            if (f.ve_mark[(long)(j / searchstep) * S + s]) {
+                if (j > centerW) {
+                    curmark = j;
+                    bp = (j >= testW) ? 1 : 0;
+                    break;
+                }
+            }
+            j += searchstep;
+        }
+        f.ve_cursor[s] = cursor;
+        f.ve_curmark[s] = curmark;
+    }
+
+    if (bp == -1) {
+        if (eofflag == 0) {   // not enough data yet
+            out[s] = d;
+            return;
+        }
+        nW = 0;
+    } else {
+        nW = (bs0 == bs1) ? 0 : bp;
+    }
+    f.nW[s] = nW;
+
+    const int bsn = nW ? bs1 : bs0;
+    const int centerNext = centerW + bsW / 4 + bsn / 4;
+    {
+        const int blockbound = centerNext + bsn / 2;
+        if (pcm_current < blockbound) {
+            out[s] = d;
+            return;
+        }
+    }
+
+    // the block (lib/block.c:606-651)
+    d.ready = 1;
+    d.lW = lW; d.W = W; d.nW = nW;
+    int blocktype;
+    if (W) {
+        blocktype = (!lW || !nW) ? 0 /* BLOCKTYPE_TRANSITION */ : 1 /* BLOCKTYPE_LONG */;
+    } else {
+        // _ve_envelope_mark (lib/envelope.c:683-707)
+        int b0 = centerW - bs0 / 4 - bs0 / 4;
+        int e0 = centerW + bs0 / 4 + bs0 / 4;
+        const int curmark = f.ve_curmark[s];
+        int marked = 0;
+        if (curmark >= b0 && curmark < e0) marked = 1;
+        else {
+            const int first = b0 / searchstep, last = e0 / searchstep;
+            for (int i = first; i < last; i++)
+                if (f.ve_mark[(long)i * S + s]) { marked = 1; break; }
+        }
+        blocktype = marked ? 0 /* BLOCKTYPE_IMPULSE */ : 1 /* BLOCKTYPE_PADDING */;
+    }
+    d.block_mode = blocktype | (W << 1);
+    d.sequence = f.sequence[s]++;
+    long long granulepos = f.granulepos[s];
+    d.granulepos = granulepos;
+    d.beginW = beginW;
+
+    if (eofflag) {
+        if (centerW >= eofflag) {
+            f.eofflag[s] = -1;
+            d.eos = 1;
+            out[s] = d;
+            return;
+        }
+    }
+
+    // advance (lib/block.c:742-808)
+    {
+        const int new_centerNext = bs1 / 2;
+        const int movementW = centerNext - new_centerNext;
+        if (movementW > 0) {
+            // _ve_envelope_shift (lib/envelope.c:709-728)
+            {
+                int ve_current = f.ve_current[s];
+                const int smallsize = ve_current / searchstep + VBM_VE_POST;
+                const int smallshift = movementW / searchstep;
+                for (int k = 0; k < smallsize - smallshift; k++)
+                    f.ve_mark[(long)k * S + s] = f.ve_mark[(long)(k + smallshift) * S + s];
+                f.ve_current[s] = ve_current - movementW;
+                int cm = f.ve_curmark[s];
+                if (cm >= 0) f.ve_curmark[s] = cm - movementW;
+                f.ve_cursor[s] -= movementW;
+            }
+            pcm_current -= movementW;
+            f.pcm_current[s] = pcm_current;
+            d.movement = movementW;
+
+            f.lW[s] = W;
+            f.W[s] = nW;
+            f.centerW[s] = new_centerNext;
+            centerW = new_centerNext;
+
+            if (eofflag) {
+                eofflag -= movementW;
+                if (eofflag <= 0) eofflag = -1;
+                f.eofflag[s] = eofflag;
+                if (centerW >= eofflag) granulepos += movementW - (centerW - eofflag);
+                else granulepos += movementW;
+            } else {
+                granulepos += movementW;
+            }
+            f.granulepos[s] = granulepos;
+        }
+    }
+    out[s] = d;
+}
+
+// ---------------------------------------------------------------------------------------------
+// blocks of one block type: dst[k][c][N] <- channel buffers of stream ids[k] at begin[k]
+__global__ void k_fe_gather(vbm_fe_state f, const int *__restrict__ ids, const int *__restrict__ begin, int count,
+                            int N, float *__restrict__ dst)
+{
+    const int kc = blockIdx.x;                      // block k, channel c
+    const int k = kc / f.ch, c = kc % f.ch;
+    if (k >= count) return;
+    const int s = ids[k];
+    // the shift of this round has not run yet: parity and contents are those the decision saw
+    const float4 *src = reinterpret_cast<const float4 *>(chan_buf(f, s, c) + begin[k]);
+    float4 *out = reinterpret_cast<float4 *>(dst + ((long)k * f.ch + c) * N);
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < N / 4; i += gridDim.y * blockDim.x) out[i] = src[i];
+}
+
+// every stream whose decision of this round moved the buffer: copy the surviving samples into the
+// other buffer; k_fe_flip then switches the parity
+__global__ void k_fe_shift(vbm_fe_state f, const vbm_fe_decision *__restrict__ dec)
+{
+    const int c = blockIdx.x;
+    const int s = c / f.ch;
+    const int mv = dec[s].movement;
+    if (mv <= 0) return;
+    const int n = f.pcm_current[s];                 // already reduced by the decision
+    const int par = f.parity[s];
+    const float4 *src = reinterpret_cast<const float4 *>(f.pcm + (long)par * f.plane + (long)c * f.cap + mv);
+    float4 *dst = reinterpret_cast<float4 *>(f.pcm + (long)(par ^ 1) * f.plane + (long)c * f.cap);
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < (n + 3) / 4; i += gridDim.y * blockDim.x) dst[i] = src[i];
+}
+
+__global__ void k_fe_flip(vbm_fe_state f, const vbm_fe_decision *__restrict__ dec)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < f.S && dec[s].movement > 0) f.parity[s] ^= 1;
+}
+
+}  // namespace
+
+#define CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? 0 : -2)
+
+extern "C" int vbm_fe_launch_append(const vbm_fe_state *f, const float *d_src, int vals, float pre_amplitude, hipStream_t st)
+{
+    const unsigned gx = (unsigned)((vals + 255) / 256);
+    hipLaunchKernelGGL(k_fe_append, dim3((unsigned)(f->S * f->ch), gx ? gx : 1), dim3(256), 0, st, *f, d_src, vals, pre_amplitude);
+    hipLaunchKernelGGL(k_fe_commit, dim3((unsigned)((f->S + 255) / 256)), dim3(256), 0, st, *f, vals);
+    return CHECK_LAUNCH();
+}
+
+extern "C" int vbm_fe_launch_extrapolate(const vbm_fe_state *f, const int *d_ids, int nids, int mode, int long_n, hipStream_t st)
+{
+    const int nstreams = mode == 0 ? f->S : nids;
+    if (nstreams <= 0) return 0;
+    hipLaunchKernelGGL(k_fe_extrapolate, dim3((unsigned)((nstreams * f->ch + 63) / 64)), dim3(64), 0, st, *f, d_ids, nids, mode, long_n);
+    hipLaunchKernelGGL(k_fe_extrapolate_commit, dim3((unsigned)((nstreams + 63) / 64)), dim3(64), 0, st, *f, d_ids, nids, mode, long_n);
+    return CHECK_LAUNCH();
+}
+
+extern "C" int vbm_fe_launch_ve_range(const vbm_fe_state *f, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_fe_ve_range, dim3((unsigned)((f->S + 255) / 256)), dim3(256), 0, st, *f);
+    return CHECK_LAUNCH();
+}
+
+extern "C" int vbm_fe_launch_ve_filter(const vbm_fe_state *f, const vbm_setup *d_setup, int t0, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_fe_ve_filter, dim3((unsigned)((f->S + 63) / 64)), dim3(64), 0, st, *f, d_setup, t0);
+    return CHECK_LAUNCH();
+}
+
+extern "C" int vbm_fe_launch_decide(const vbm_fe_state *f, const vbm_setup *d_setup, vbm_fe_decision *d_out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_fe_decide, dim3((unsigned)((f->S + 63) / 64)), dim3(64), 0, st, *f, d_setup, d_out);
+    return CHECK_LAUNCH();
+}
+
+extern "C" int vbm_fe_launch_gather(const vbm_fe_state *f, const int *d_ids, const int *d_begin, int count, int N,
+                                    float *d_dst, hipStream_t st)
+{
+    if (count <= 0) return 0;
+    hipLaunchKernelGGL(k_fe_gather, dim3((unsigned)(count * f->ch), (unsigned)((N / 4 + 255) / 256)), dim3(256), 0, st, *f,
+                       d_ids, d_begin, count, N, d_dst);
+    return CHECK_LAUNCH();
+}
+
+extern "C" int vbm_fe_launch_shift(const vbm_fe_state *f, const vbm_fe_decision *d_dec, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_fe_shift, dim3((unsigned)(f->S * f->ch), 4), dim3(256), 0, st, *f, d_dec);
+    hipLaunchKernelGGL(k_fe_flip, dim3((unsigned)((f->S + 255) / 256)), dim3(256), 0, st, *f, d_dec);
+    return CHECK_LAUNCH();
+}

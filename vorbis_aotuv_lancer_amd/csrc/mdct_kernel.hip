@@ -123,15 +123,30 @@ template <int N>
 struct Geo {
     static constexpr int C = N / 4;          // complex values per block after the fold
     static constexpr int BPG = 512 / C;      // blocks per 512-complex group
-    static constexpr int LOG2C = (N == 2048) ? 9 : 6;
+    static constexpr int LOG2C = (N == 2048) ? 9 : (N == 256 ? 6 : 5);
     static constexpr int R2 = 3 * N / 16;    // first pair of fold region 3
     static constexpr int R1 = N / 16;        // first pair of fold region 2
 };
 
-// group of four 16-B loads -> registers
+// first sample of block `blk`: rows of a block-major array, or (N == 128, envelope search) the
+// 128-sample window of search step first[stream] + t0 + t inside a channel's PCM buffer, blk =
+// channel * steps + t; nullptr when that step does not exist
+__device__ __forceinline__ const float *block_src(const float *__restrict__ pcm, long blk, int n,
+                                                  const vbm_ve_gather &g)
+{
+    if (!g.first) return pcm + blk * n;
+    const long c = blk / g.steps;
+    const int t = (int)(blk - c * g.steps);
+    const int s = (int)(c / g.ch);
+    const int j = g.first[s] + g.t0 + t;
+    if (j >= g.last[s]) return nullptr;
+    return pcm + (long)g.parity[s] * g.plane + c * g.cap + (long)j * 64;
+}
+
+// group of eight 16-B loads -> registers
 template <int N>
 __device__ __forceinline__ void issue_loads(float4 (&v)[8], const float *__restrict__ pcm,
-                                            long group, long nblocks, int lane)
+                                            long group, long nblocks, int lane, const vbm_ve_gather &g)
 {
     using G = Geo<N>;
 #pragma unroll
@@ -140,8 +155,9 @@ __device__ __forceinline__ void issue_loads(float4 (&v)[8], const float *__restr
         int b = P / G::C, p = P % G::C;
         int q0 = (p < G::R2) ? (G::R2 - 1 - p) : (7 * N / 16 - 1 - p);
         long blk = group * G::BPG + b;
-        if (blk < nblocks)
-            v[k] = *reinterpret_cast<const float4 *>(pcm + blk * N + 4 * q0);
+        const float *src = (blk < nblocks) ? block_src(pcm, blk, N, g) : nullptr;
+        if (src)
+            v[k] = *reinterpret_cast<const float4 *>(src + 4 * q0);
         else
             v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -154,14 +170,15 @@ void k_window_mdct(const float *__restrict__ pcm, float *__restrict__ out,
                    const float *__restrict__ trig_g,    // N + N/4 floats, lib/mdct.c:67-76
                    const float *__restrict__ win_self,  // rising half-window of size N   (N/2 floats)
                    const float *__restrict__ win_short, // rising half-window of the short size (short_n/2 floats), N == 2048 only
-                   int short_n, int apply_window, long nblocks)
+                   int short_n, int apply_window,       // 0 none, 1 Vorbis window (lW/nW shapes), 2 = win_self is a full N-sample table
+                   long nblocks, vbm_ve_gather gather)
 {
     using G = Geo<N>;
     constexpr int C = G::C;
     constexpr int NTRIG = N + N / 4;
 
     __shared__ __attribute__((aligned(16))) float s_trig[NTRIG];
-    __shared__ __attribute__((aligned(16))) float s_win[N / 2];
+    __shared__ __attribute__((aligned(16))) float s_win[(N == 128) ? N : N / 2];
     __shared__ __attribute__((aligned(16))) float s_wshort[(N == 2048) ? 1024 : 4];
     __shared__ __attribute__((aligned(16))) float2 s_x[WAVES_PER_WG][SLOTS];
 
@@ -171,7 +188,8 @@ void k_window_mdct(const float *__restrict__ pcm, float *__restrict__ out,
 
     for (int i = tid; i < NTRIG; i += blockDim.x) s_trig[i] = trig_g[i];
     if (apply_window) {
-        for (int i = tid; i < N / 2; i += blockDim.x) s_win[i] = win_self[i];
+        const int wn = (apply_window == 2 && N == 128) ? N : N / 2;
+        for (int i = tid; i < wn; i += blockDim.x) s_win[i] = win_self[i];
         if (N == 2048)
             for (int i = tid; i < (short_n >> 1); i += blockDim.x) s_wshort[i] = win_short[i];
     }
@@ -184,7 +202,7 @@ void k_window_mdct(const float *__restrict__ pcm, float *__restrict__ out,
     const float scale = 4.f / N;
 
     float4 v[8];
-    if (group < ngroups) issue_loads<N>(v, pcm, group, nblocks, lane);
+    if (group < ngroups) issue_loads<N>(v, pcm, group, nblocks, lane, gather);
 
     for (; group < ngroups; group += gstride) {
         // ---------------- window + odd-sample exchange -----------------------------
@@ -195,7 +213,10 @@ void k_window_mdct(const float *__restrict__ pcm, float *__restrict__ out,
             int b = P / C, p = P % C;
             int q0 = (p < G::R2) ? (G::R2 - 1 - p) : (7 * N / 16 - 1 - p);
             float4 d = v[k];
-            if (apply_window) {
+            if (apply_window == 2 && N == 128) {
+                float4 w = *reinterpret_cast<const float4 *>(s_win + 4 * q0);   // lib/envelope.c:124
+                d = make_float4(d.x * w.x, d.y * w.y, d.z * w.z, d.w * w.w);
+            } else if (apply_window) {
                 int ln = N, rn = N;
                 const float *wl = s_win, *wr = s_win;
                 if (N == 2048 && wflags) {
@@ -231,7 +252,7 @@ void k_window_mdct(const float *__restrict__ pcm, float *__restrict__ out,
             c[k].x = r1 * T.y + r0 * T.x;
             c[k].y = r1 * T.x - r0 * T.y;
         }
-        if (next < ngroups) issue_loads<N>(v, pcm, next, nblocks, lane);
+        if (next < ngroups) issue_loads<N>(v, pcm, next, nblocks, lane, gather);
         wave_lds_sync();  // exchange slots are reused below
 
         // ---------------- round A: index bits 8,7,6 (long blocks only) ----------------
@@ -264,12 +285,14 @@ void k_window_mdct(const float *__restrict__ pcm, float *__restrict__ out,
             const int base = (lane >> 3) * 64 + (lane & 7);
 #pragma unroll
             for (int k = 0; k < 8; k++) c[k] = sx[slot_addr(base + 8 * k)];
-            constexpr int MUL0 = 4 << (G::LOG2C - 6);  // trigint of the 64-complex stage
+            constexpr int MUL0 = (G::LOG2C >= 6) ? (4 << (G::LOG2C >= 6 ? G::LOG2C - 6 : 0)) : 0;  // trigint of the 64-complex stage
             constexpr int MUL1 = 4 << (G::LOG2C - 5);  // trigint of the 32-complex stage
+            if (G::LOG2C >= 6) {   // 128-point blocks (32 complex) have no 64-complex stage
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                int t = 31 - ((lane & 7) + 8 * k);
-                bfly(c[k], c[k + 4], *reinterpret_cast<const float2 *>(s_trig + MUL0 * t));
+                for (int k = 0; k < 4; k++) {
+                    int t = 31 - ((lane & 7) + 8 * k);
+                    bfly(c[k], c[k + 4], *reinterpret_cast<const float2 *>(s_trig + MUL0 * t));
+                }
             }
 #pragma unroll
             for (int kb = 0; kb < 8; kb += 4)
@@ -391,6 +414,7 @@ extern "C" int vbm_launch_window_mdct(const float *d_pcm, float *d_out, const ui
 {
     if (nblocks <= 0) return 0;
     if (n != 2048 && n != 256) return -1;
+    const vbm_ve_gather none = {};
     const int bpg = (n == 2048) ? 1 : 8;
     long ngroups = (nblocks + bpg - 1) / bpg;
     long wgs = (ngroups + WAVES_PER_WG - 1) / WAVES_PER_WG;
@@ -399,9 +423,23 @@ extern "C" int vbm_launch_window_mdct(const float *d_pcm, float *d_out, const ui
     dim3 grid((unsigned)wgs), block(64 * WAVES_PER_WG);
     if (n == 2048)
         hipLaunchKernelGGL(k_window_mdct<2048>, grid, block, 0, stream, d_pcm, d_out, d_wflags,
-                           d_trig, d_win_self, d_win_short, short_n, apply_window, nblocks);
+                           d_trig, d_win_self, d_win_short, short_n, apply_window, nblocks, none);
     else
         hipLaunchKernelGGL(k_window_mdct<256>, grid, block, 0, stream, d_pcm, d_out, d_wflags,
-                           d_trig, d_win_self, d_win_short, short_n, apply_window, nblocks);
+                           d_trig, d_win_self, d_win_short, short_n, apply_window, nblocks, none);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// 128-point search MDCTs of the envelope detector (lib/envelope.c:121-125): blocks are addressed
+// through `g` (channel * g.steps + t), out[blk][64]
+extern "C" int vbm_launch_ve_mdct(const vbm_ve_gather *g, float *d_out, const float *d_trig, const float *d_win,
+                                  long nblocks, hipStream_t stream)
+{
+    if (nblocks <= 0) return 0;
+    long ngroups = (nblocks + 15) / 16;
+    long wgs = (ngroups + WAVES_PER_WG - 1) / WAVES_PER_WG;
+    if (wgs > 256 * 8) wgs = 256 * 8;
+    hipLaunchKernelGGL(k_window_mdct<128>, dim3((unsigned)wgs), dim3(64 * WAVES_PER_WG), 0, stream, g->pcm, d_out,
+                       (const uint8_t *)nullptr, d_trig, d_win, (const float *)nullptr, 0, 2, nblocks, *g);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -100,6 +100,25 @@ struct vbm_map {
     int coupling_mag[16], coupling_ang[16];
 };
 
+// envelope detector look (reference lib/envelope.h:27-76, _ve_envelope_init lib/envelope.c:42-87)
+#define VBM_VE_BANDS 12
+#define VBM_VE_PRE 16
+#define VBM_VE_WIN 4
+#define VBM_VE_POST 2
+#define VBM_VE_AMP (VBM_VE_PRE + VBM_VE_POST - 1)
+#define VBM_VE_NEARDC 15
+#define VBM_VE_MINSTRETCH 2
+#define VBM_VE_MAXSTRETCH 12
+#define VBM_VE_MAXBAND 8
+struct vbm_envelope {
+    float preecho_thresh[VBM_VE_BANDS], postecho_thresh[VBM_VE_BANDS];
+    float stretch_penalty, minenergy;
+    int band_begin[VBM_VE_BANDS], band_end[VBM_VE_BANDS];
+    float band_window[VBM_VE_BANDS][VBM_VE_MAXBAND], band_total[VBM_VE_BANDS];
+    const float *mdct_win;           // 128: sin^2 window of the 128-point search MDCT
+    const float *mdct_trig;          // 128 + 32
+};
+
 struct vbm_setup {
     int channels;
     long rate;
@@ -126,4 +145,5 @@ struct vbm_setup {
     const float *window[2];          // rising half-windows of blocksizes[0], [1]
     const float *mdct_trig[2];       // n + n/4
     const float *fft_wa[2];          // n
+    vbm_envelope ve;
 };

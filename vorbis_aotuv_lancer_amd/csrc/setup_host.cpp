@@ -461,6 +461,8 @@ static void rebase_setup(vbm_setup &s, const unsigned char *base)
         rebase(s.mdct_trig[i], base);
         rebase(s.fft_wa[i], base);
     }
+    rebase(s.ve.mdct_win, base);
+    rebase(s.ve.mdct_trig, base);
 }
 
 static void rebase_book(vbm_book &b, const unsigned char *base)
@@ -686,6 +688,35 @@ vbm_setup_host *vbm_setup_host_load(const char *common_path, const char *mode_pa
             vbm_host_fft_twiddles(N, wa.data());
             s.mdct_trig[b] = as_off<float>(A.put(trig));
             s.fft_wa[b] = as_off<float>(A.put(wa));
+        }
+        // ---- envelope detector look (lib/envelope.c:42-87)
+        {
+            vbm_envelope &ve = s.ve;
+            memcpy(ve.preecho_thresh, mode.f32("psy_g/preecho_thresh"), sizeof(ve.preecho_thresh));
+            memcpy(ve.postecho_thresh, mode.f32("psy_g/postecho_thresh"), sizeof(ve.postecho_thresh));
+            ve.stretch_penalty = mode.f32("psy_g/floats")[0];
+            ve.minenergy = mode.f32("psy_g/floats")[1];
+            const int *bb = common.i32("envelope/band_begin"), *be = common.i32("envelope/band_end");
+            for (int j = 0; j < VBM_VE_BANDS; j++) {
+                ve.band_begin[j] = bb[j];
+                ve.band_end[j] = be[j];
+                if (be[j] > VBM_VE_MAXBAND || bb[j] + be[j] > 32) throw std::string("envelope band out of range");
+                float total = 0.f;
+                for (int i = 0; i < VBM_VE_MAXBAND; i++) ve.band_window[j][i] = 0.f;
+                for (int i = 0; i < be[j]; i++) {
+                    ve.band_window[j][i] = (float)sin(((double)i + .5) / (double)be[j] * M_PI);
+                    total += ve.band_window[j][i];
+                }
+                ve.band_total[j] = (float)(1. / (double)total);
+            }
+            std::vector<float> win(128), trig(128 + 32);
+            for (int i = 0; i < 128; i++) {
+                float t = (float)sin((double)i / (128 - 1.) * M_PI);
+                win[i] = t * t;
+            }
+            vbm_host_mdct_trig(128, trig.data());
+            ve.mdct_win = as_off<float>(A.put(win));
+            ve.mdct_trig = as_off<float>(A.put(trig));
         }
         // the book array itself also lives in the arena (device view is rebased separately)
         H->books_off = A.put(H->books);

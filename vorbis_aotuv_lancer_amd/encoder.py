@@ -116,3 +116,59 @@ class Encoder:
         if self._h:
             lib.vbm_encoder_destroy(self._h)
             self._h = C.c_void_p()
+
+
+class PacketInfo(C.Structure):
+    """vbm_packet_info (include/vorbis_mi355x.h)"""
+    _fields_ = [("stream", C.c_int), ("block_mode", C.c_int), ("lW", C.c_int), ("W", C.c_int), ("nW", C.c_int),
+                ("eos", C.c_int), ("granulepos", C.c_longlong), ("packetno", C.c_longlong)]
+
+
+class FrontEnd:
+    """Stream front end of an Encoder: vorbis_analysis_buffer/_wrote/_blockout (+ envelope detector) for
+    all its streams on the device, feeding vbm_analysis_batch (reference lib/block.c:405-812,
+    lib/envelope.c; examples/encoder_example.c:190-235 is the loop this mirrors)."""
+
+    def __init__(self, encoder):
+        self.enc = encoder
+        self._h = C.c_void_p()
+        check(lib.vbm_frontend_create(C.byref(self._h), encoder._h), "vbm_frontend_create")
+        self._info = (PacketInfo * encoder.nstreams)()
+
+    def reset(self):
+        check(lib.vbm_frontend_reset(self._h), "vbm_frontend_reset")
+
+    def write(self, pcm):
+        """pcm: CUDA float32 [nstreams, channels, vals] — `vals` new samples for every stream."""
+        S, ch = self.enc.nstreams, self.enc.setup.channels
+        if not (pcm.is_cuda and pcm.dtype == torch.float32 and pcm.is_contiguous() and pcm.dim() == 3
+                and pcm.shape[0] == S and pcm.shape[1] == ch):
+            raise ValueError(f"pcm must be a contiguous CUDA float32 tensor of shape ({S}, {ch}, vals)")
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(lib.vbm_frontend_write(self._h, pcm.data_ptr(), int(pcm.shape[2]), st), "vbm_frontend_write")
+
+    def finish(self, stream_ids=None):
+        """vorbis_analysis_wrote(vd, 0) for the listed streams (default: all)."""
+        ids = np.arange(self.enc.nstreams, dtype=np.int32) if stream_ids is None else \
+            np.ascontiguousarray(stream_ids, dtype=np.int32)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(lib.vbm_frontend_finish(self._h, ids.ctypes.data, len(ids), st), "vbm_frontend_finish")
+
+    def encode_round(self, device=None):
+        """One blockout round over all streams.  Returns (info list, packets uint8 [n, max_bytes], nbytes int32
+        [n]) for the n blocks that came out (n may be 0: every stream needs more PCM)."""
+        dev = device or torch.device("cuda", torch.cuda.current_device())
+        S = self.enc.nstreams
+        packets = torch.empty((S, self.enc.max_packet_bytes), dtype=torch.uint8, device=dev)
+        nbytes = torch.empty((S,), dtype=torch.int32, device=dev)
+        n = C.c_int()
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(lib.vbm_frontend_encode_round(self._h, packets.data_ptr(), nbytes.data_ptr(), self._info, C.byref(n), st),
+              "vbm_frontend_encode_round")
+        k = n.value
+        return [self._info[i] for i in range(k)], packets[:k], nbytes[:k]
+
+    def close(self):
+        if self._h:
+            lib.vbm_frontend_destroy(self._h)
+            self._h = C.c_void_p()
