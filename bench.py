@@ -37,6 +37,7 @@ QUALITY = 0.5
 N_LONG = 2048
 HOP = N_LONG // 2
 SPLIT = int(os.environ.get("VBM_BENCH_SPLIT", "1"))   # sub-batches per step, one HIP stream each
+MAX_ROUNDS = int(os.environ.get("VBM_BENCH_MAX_ROUNDS", "2"))   # --from-pcm: blockout rounds per write
 DISTINCT_STEPS = 8              # PCM for this many consecutive blocks per stream is kept in HBM
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -96,6 +97,9 @@ def main():
     ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--from-pcm", action="store_true",
+                    help="time the whole encoder from raw PCM (stream front end: envelope search + block "
+                         "carve-out on the device, SURVEY 8f N1) instead of the per-block path alone")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -131,7 +135,54 @@ def main():
     wflags = np.full(per, 3, dtype=np.uint8)   # lW = nW = long
     parts = [[blk[p * per:(p + 1) * per] for blk in blocks] for p in range(SPLIT)]   # contiguous views
 
+    fe = None
+    if args.from_pcm:
+        # one continuous signal per stream, cut into 1024-sample writes (23.2 ms of audio per step)
+        assert SPLIT == 1
+        g = torch.Generator(device=dev).manual_seed(99 + rank)
+        nchunks = args.steps + args.warmup
+        t = torch.arange(nchunks * HOP, device=dev, dtype=torch.float32) / RATE
+        f1 = 110.0 + 1650.0 * torch.rand((STREAMS_PER_GPU, 1, 1), generator=g, device=dev)
+        f2 = 2000.0 + 4000.0 * torch.rand((STREAMS_PER_GPU, 1, 1), generator=g, device=dev)
+        chan = torch.arange(1, CHANNELS + 1, device=dev, dtype=torch.float32).view(1, CHANNELS, 1)
+        chunks = []
+        for k in range(nchunks):
+            tk = t[k * HOP:(k + 1) * HOP]
+            x = 0.3 * torch.sin(2 * np.pi * f1 * chan * tk) + 0.2 * torch.sin(2 * np.pi * f2 * tk + chan)
+            x += 0.05 * (2 * torch.rand((STREAMS_PER_GPU, CHANNELS, HOP), generator=g, device=dev) - 1)
+            chunks.append(x.contiguous())
+        fe = v.FrontEnd(enc)
+        round_count = [0, 0]
+
     def step(k):
+        if fe is not None:
+            # Round policy: a stream inside a run of short blocks has up to 8 blocks per write, each in its
+            # own round, and such rounds hold a handful of blocks.  Two rounds per write keep every stream
+            # ahead of its input on average (a lagging stream gains one block per step); more only while
+            # some buffer is past half of its capacity.
+            trace = os.environ.get("VBM_BENCH_TRACE")
+            if trace:
+                torch.cuda.synchronize(); t_a = time.perf_counter()
+            fe.write(chunks[k])
+            out = None
+            rounds = 0
+            while True:
+                info, pk_, nb_ = fe.encode_round(dev)
+                if trace:
+                    torch.cuda.synchronize(); t_b = time.perf_counter()
+                    print(f"step {k} round {rounds}: {len(info)} blocks, modes "
+                          f"{np.bincount(info['block_mode'], minlength=4).tolist() if len(info) else []}, "
+                          f"{(t_b - t_a) * 1e3:.2f} ms, max_buffered {fe.max_buffered}", file=sys.stderr)
+                    t_a = t_b
+                if len(info) == 0:
+                    break
+                out = (pk_, nb_) if out is None else out
+                rounds += 1
+                round_count[0] += 1
+                round_count[1] += len(info)
+                if rounds >= MAX_ROUNDS and fe.max_buffered + HOP <= fe.capacity // 2:
+                    break
+            return out
         out = None
         for p in range(SPLIT):
             with torch.cuda.stream(queues[p]):
@@ -150,7 +201,9 @@ def main():
         each.profile_begin(args.steps)  # HIP events between the stage kernels, on the stream each is launched on
     t0 = time.perf_counter()
     for k in range(args.steps):
-        pk, nb = step(args.warmup + k)
+        res = step(args.warmup + k)
+        if res is not None:
+            pk, nb = res
     barrier()
     dt = time.perf_counter() - t0
     stage_ms, calls = enc.profile_end()
@@ -212,8 +265,14 @@ def main():
                 "channel_blocks_per_step": ncb * world,
                 "stages": list(stage_ms.keys()),
                 "pipeline_complete": True,
-                "block_switching": "not in the timed region (long blocks only; envelope search / carve-out is "
-                                   "SURVEY.md §8f N1)",
+                "from_pcm": bool(args.from_pcm),
+                **({"blocks_encoded": round_count[1], "rounds": round_count[0], "max_rounds_per_write": MAX_ROUNDS}
+                   if args.from_pcm else {}),
+                "block_switching": ("in the timed region: PCM intake, envelope search and block carve-out run on the "
+                                    "device (vbm_frontend_*); one 1024-sample write per stream per step"
+                                    if args.from_pcm else
+                                    "not in the timed region (long blocks only; --from-pcm times the stream front "
+                                    "end as well)"),
                 "mean_packet_bytes": mean_bytes,
                 "parallelism": f"stream-shard x{world} (no collective); {SPLIT} sub-batch(es) of {per} streams per "
                                "step on separate HIP streams",

@@ -136,6 +136,16 @@ int vbm_encoder_max_packet_bytes(const vbm_encoder *enc);
 int vbm_analysis_batch(vbm_encoder *enc, int block_mode, int nsb, const int *stream_ids,
                        const uint8_t *wflags, const float *d_pcm, uint8_t *d_packets,
                        int *d_packet_bytes, void *stream);
+/* One ROUND: blocks of all four block types at once (what one pass of vorbis_analysis_blockout over
+ * all streams yields).  counts[m] blocks of type m; stream_ids / wflags (host) grouped by type, type
+ * 0 first; d_pcm: the blocks of type m start at float offset (number of blocks of lower types) *
+ * channels * blocksizes[1] and lie [count][channels][N_m].  A stream may appear once per round.
+ * The four batches run side by side on internal HIP streams (forked from and joined back to
+ * `stream`), so the few
+ * short blocks of a round cost no more than the long-block batch beside them.  Packets come back in
+ * the grouped order: d_packets[k][max_packet_bytes], d_packet_bytes[k]. */
+int vbm_analysis_round(vbm_encoder *enc, const int *counts, const int *stream_ids, const uint8_t *wflags,
+                       const float *d_pcm, uint8_t *d_packets, int *d_packet_bytes, void *stream);
 /* Stage intermediates of the LAST batch as block-major rows ([channel-block][rows]) for parity
  * tests: "mdct_raw" "logfft" "logmdct" "noise" "tone" "logmask" "mdct" "epeak" "npeak" "post"
  * "floor_out" "residue", and the vectors "local_ampmax" "global_ampmax" "post_valid" "nonzero"
@@ -166,6 +176,10 @@ int vbm_encoder_sub_batches(const vbm_encoder *enc);
  *     do vbm_frontend_encode_round(fe, d_pkt, d_len, info, &n, q);  // <= 1 block per stream per round
  *     while (n > 0);
  *     ... vbm_frontend_finish(fe, ids, k, q) = vorbis_analysis_wrote(vd, 0), then rounds until n == 0.
+ * Rounds may be deferred (a stream inside a run of short blocks yields up to 8 blocks per 1024
+ * samples; blocks and packets do not depend on when the rounds run), but drain completely before
+ * vbm_frontend_finish: like the reference (lib/block.c:531-541) it fits the end-of-stream LPC to the
+ * samples the buffer holds at that moment.
  * The block sequence (lW, W, nW, block type, granulepos, packetno, e_o_s) and the packets are those
  * of the reference's scalar build for the same PCM.  d_pcm: device float, [nstreams][channels][vals].
  * encode_round: packets of the round in d_packets[k][max_packet_bytes] / d_packet_bytes[k],
@@ -187,6 +201,11 @@ void vbm_frontend_destroy(vbm_frontend *fe);
 int vbm_frontend_reset(vbm_frontend *fe);
 int vbm_frontend_write(vbm_frontend *fe, const float *d_pcm, int vals, void *stream);
 int vbm_frontend_finish(vbm_frontend *fe, const int *stream_ids, int n, void *stream);
+/* Buffer occupancy, for callers that do not drain completely after every write (a stream inside a
+ * run of short blocks yields up to 8 blocks per 1024 samples, each in its own round): the most
+ * samples any stream holds now, and the occupancy a write may not exceed (VBM_EINVAL beyond it). */
+int vbm_frontend_max_buffered(const vbm_frontend *fe);
+int vbm_frontend_capacity(const vbm_frontend *fe);
 int vbm_frontend_encode_round(vbm_frontend *fe, uint8_t *d_packets, int *d_packet_bytes,
                               vbm_packet_info *info, int *nblocks, void *stream);
 

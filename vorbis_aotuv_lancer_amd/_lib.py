@@ -45,6 +45,8 @@ SIGNATURES = {
     "vbm_encoder_max_packet_bytes": (C.c_int, [C.c_void_p]),
     "vbm_analysis_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p]),
+    "vbm_analysis_round": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p]),
     "vbm_encoder_fetch": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_char),
                                     C.c_void_p]),
     "vbm_encoder_profile_begin": (C.c_int, [C.c_void_p, C.c_int]),
@@ -56,6 +58,8 @@ SIGNATURES = {
     "vbm_frontend_reset": (C.c_int, [C.c_void_p]),
     "vbm_frontend_write": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vbm_frontend_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "vbm_frontend_max_buffered": (C.c_int, [C.c_void_p]),
+    "vbm_frontend_capacity": (C.c_int, [C.c_void_p]),
     "vbm_frontend_encode_round": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]),
     "vbm_encoder_stage_count": (C.c_int, []),
     "vbm_encoder_stage_name": (C.c_char_p, [C.c_int]),

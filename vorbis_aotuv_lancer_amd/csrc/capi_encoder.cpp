@@ -122,8 +122,10 @@ extern "C" int vbm_encoder_create(vbm_encoder **out, vbm_setup_handle *setup, in
     e->S = nstreams;
     e->ch = s->channels;
     e->cap = max_batch;
-    e->L = round64(max_batch * e->ch);
-    e->Ls = round64(max_batch);
+    // lanes: the batch capacity plus padding for vbm_analysis_round, which starts every block type of a
+    // round on a tile boundary (4 types -> up to 3 x 63 lanes of padding)
+    e->L = round64((max_batch + 256) * e->ch);
+    e->Ls = round64(max_batch + 256);
     e->max_packet_bytes = 4096 * ((e->ch + 1) / 2);   // generous: q10 stereo long blocks stay < 3 KB
     e->max_oct = 0;
     for (int i = 0; i < s->psys; i++)
@@ -484,6 +486,114 @@ extern "C" int vbm_analysis_batch(vbm_encoder *e, int block_mode, int nsb, const
     }
     if (prof) e->prof_calls++;
 #undef STAGE
+#undef RUN
+    return VBM_OK;
+}
+
+// One round of blocks of all four block types: counts[m] blocks of type m, described by stream_ids /
+// wflags grouped by type (type 0 first); d_pcm: the blocks of type m start at float offset
+// (blocks of lower types) * channels * blocksizes[1] and lie block-major [count][channels][N_m].
+// The four batches are independent (different streams), so each runs on its own internal HIP stream
+// on a tile-aligned slice of the workspace; a handful of short blocks then costs the round no more
+// than the big long-block batch it runs beside.  Outputs are compact: packet k of the grouped order.
+extern "C" int vbm_analysis_round(vbm_encoder *e, const int *counts, const int *stream_ids, const uint8_t *wflags,
+                                  const float *d_pcm, uint8_t *d_packets, int *d_packet_bytes, void *stream)
+{
+    if (!e || !counts || !stream_ids || !wflags || !d_pcm) return VBM_EINVAL;
+    if (((uintptr_t)d_pcm & 15) || ((uintptr_t)d_packets & 3)) return VBM_EINVAL;
+    const vbm_setup *s = e->hs;
+    int total = 0, off[4], pad[4], lanes = 0;
+    for (int m = 0; m < 4; m++) {
+        if (counts[m] < 0) return VBM_EINVAL;
+        off[m] = total;
+        pad[m] = lanes;
+        total += counts[m];
+        lanes = (lanes + counts[m] + 63) & ~63;
+        if (counts[m] && s->modes < 2 && (m >> 1)) return VBM_EINVAL;
+    }
+    if (total == 0) return VBM_OK;
+    if (total > e->cap || lanes > e->Ls) return VBM_EINVAL;
+    for (int i = 0; i < total; i++)
+        if (stream_ids[i] < 0 || stream_ids[i] >= e->S) return VBM_EINVAL;
+    int rc = vbm_encoder_set_sub_batches(e, e->nsplit);   // make sure the internal streams exist
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t err;
+    // ids / flags in the padded lane layout, through the pinned staging (always uploaded: the layout changes
+    // from round to round)
+    {
+        const int t = e->stage_turn;
+        e->stage_turn ^= 1;
+        (void)hipEventSynchronize(e->ev_stage[t]);
+        memset(e->h_ids[t], 0, lanes * sizeof(int));
+        memset(e->h_flags[t], 0, lanes);
+        for (int m = 0; m < 4; m++) {
+            memcpy(e->h_ids[t] + pad[m], stream_ids + off[m], counts[m] * sizeof(int));
+            memcpy(e->h_flags[t] + pad[m], wflags + off[m], counts[m]);
+        }
+        if ((err = hipMemcpyAsync(e->d_stream_id, e->h_ids[t], lanes * sizeof(int), hipMemcpyHostToDevice, st)) != hipSuccess ||
+            (err = hipMemcpyAsync(e->d_wflags, e->h_flags[t], lanes, hipMemcpyHostToDevice, st)) != hipSuccess)
+            return vbm_set_hip_error(err, "hipMemcpyAsync(round ids)");
+        (void)hipEventRecord(e->ev_stage[t], st);
+        e->last_ids.clear();
+        e->last_flags.clear();
+    }
+    if ((err = hipEventRecord(e->ev_fork, st)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
+    e->last_nsb = 0;
+#define RUN(x) do { rc = (x); if (rc) { g_vbm_err = std::string("launch failed: ") + #x; return VBM_EHIP; } } while (0)
+    // Every block type gets its own internal stream; the largest batch is enqueued first so that its
+    // launches are in flight while the host issues the ~35 launches of each small batch.  Measured
+    // alternatives on MI355X: big batch on the caller's stream + one side stream, and two
+    // streams with disjoint CU masks (hipExtStreamCreateWithCUMask) — both slower: the single-wavefront
+    // kernels of the small batches run several times slower beside the wide kernels of the big batch, so
+    // their chains are better run next to each other than one after another.
+    while ((int)e->sub.size() < 4) {
+        hipStream_t q;
+        hipEvent_t ev;
+        if (hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return VBM_EHIP;
+        e->sub.push_back(q);
+        e->ev_join.push_back(ev);
+    }
+    int order[4] = {0, 1, 2, 3};
+    for (int a = 0; a < 4; a++)
+        for (int c = a + 1; c < 4; c++)
+            if (counts[order[c]] > counts[order[a]]) { int t_ = order[a]; order[a] = order[c]; order[c] = t_; }
+    for (int rank = 0; rank < 4; rank++) {
+        const int m = order[rank];
+        if (!counts[m]) continue;
+        hipStream_t q = e->sub[m];
+        if ((err = hipStreamWaitEvent(q, e->ev_fork, 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
+        vbm_batch full;
+        configure(e, full, m, counts[m], d_pcm);
+        vbm_batch v = slice_of(full, pad[m], counts[m]);
+        v.pcm = d_pcm + (size_t)off[m] * e->ch * s->blocksizes[1];
+        const int W = v.W;
+        RUN(vbm_launch_spread_flags(&v, q));
+        RUN(vbm_launch_window_mdct(v.pcm, v.mdct_bm, W ? v.wflags_cb : nullptr, vbm_setup_device_ptrs(e->H)->mdct_trig[W],
+                                   vbm_setup_device_ptrs(e->H)->window[W], vbm_setup_device_ptrs(e->H)->window[0], v.N,
+                                   s->blocksizes[0], 1, v.ncb, 0, q));
+        RUN(vbm_launch_window_fft_log(v.pcm, v.logfft_bm, v.local_ampmax, W ? v.wflags_cb : nullptr,
+                                      vbm_setup_device_ptrs(e->H)->fft_wa[W], vbm_setup_device_ptrs(e->H)->window[W],
+                                      vbm_setup_device_ptrs(e->H)->window[0], v.N, s->blocksizes[0], v.ncb, q));
+        RUN(vbm_launch_transpose_in(&v, q));
+        RUN(vbm_launch_prologue(&v, q));
+        RUN(vbm_launch_noisemask(&v, q));
+        RUN(vbm_launch_tonemask(&v, q));
+        RUN(vbm_launch_mix(&v, q));
+        RUN(vbm_launch_floor_fit(&v, q));
+        RUN(vbm_launch_floor_encode(&v, q));
+        RUN(vbm_launch_couple_quantize(&v, q));
+        RUN(vbm_launch_pack(&v, q));
+        if (d_packets)
+            RUN(vbm_launch_untranspose_i32((const int *)v.packetT, (int *)(d_packets + (size_t)off[m] * e->max_packet_bytes),
+                                           e->max_packet_bytes / 4, (size_t)(e->max_packet_bytes / 4) * 64, v.nsb, q));
+        if (d_packet_bytes &&
+            (err = hipMemcpyAsync(d_packet_bytes + off[m], v.packet_bytes, v.nsb * sizeof(int), hipMemcpyDeviceToDevice, q)) != hipSuccess)
+            return vbm_set_hip_error(err, "hipMemcpyAsync(packet_bytes)");
+        if ((err = hipEventRecord(e->ev_join[m], q)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
+        if ((err = hipStreamWaitEvent(st, e->ev_join[m], 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
+    }
 #undef RUN
     return VBM_OK;
 }

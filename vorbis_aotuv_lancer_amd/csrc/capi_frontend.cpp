@@ -158,6 +158,22 @@ extern "C" int vbm_frontend_reset(vbm_frontend *fe)
     return VBM_OK;
 }
 
+// most samples any stream holds (host mirror of pcm_current): lets the caller bound the rounds it runs
+// per write and still drain before the buffers fill
+extern "C" int vbm_frontend_max_buffered(const vbm_frontend *fe)
+{
+    if (!fe) return VBM_EINVAL;
+    int m = 0;
+    for (int i = 0; i < fe->S; i++)
+        if (fe->pcm_current[i] > m) m = fe->pcm_current[i];
+    return m;
+}
+
+extern "C" int vbm_frontend_capacity(const vbm_frontend *fe)
+{
+    return fe ? (int)(fe->f.cap - 3 * fe->hs->blocksizes[1]) : VBM_EINVAL;
+}
+
 extern "C" int vbm_frontend_write(vbm_frontend *fe, const float *d_pcm, int vals, void *stream)
 {
     if (!fe || !d_pcm || vals <= 0) return VBM_EINVAL;
@@ -290,16 +306,15 @@ extern "C" int vbm_frontend_encode_round(vbm_frontend *fe, uint8_t *d_packets, i
         (err = hipMemcpyAsync(fe->d_begin, fe->h_begin, total * sizeof(int), hipMemcpyHostToDevice, st)) != hipSuccess)
         return vbm_set_hip_error(err, "hipMemcpyAsync(round lists)");
 
-    const int maxb = vbm_encoder_max_packet_bytes(fe->enc);
     for (int m = 0; m < 4; m++) {
         if (!count[m]) continue;
         const int N = (m >> 1) ? bs1 : bs0;
         float *blocks = fe->d_blocks + (size_t)offset[m] * ch * bs1;
         if (vbm_fe_launch_gather(&fe->f, fe->d_ids + offset[m], fe->d_begin + offset[m], count[m], N, blocks, st))
             return VBM_EHIP;
-        int rc = vbm_analysis_batch(fe->enc, m, count[m], fe->h_ids + offset[m], fe->h_flags + offset[m], blocks,
-                                    d_packets ? d_packets + (size_t)offset[m] * maxb : nullptr,
-                                    d_packet_bytes ? d_packet_bytes + offset[m] : nullptr, stream);
+    }
+    {
+        int rc = vbm_analysis_round(fe->enc, count, fe->h_ids, fe->h_flags, fe->d_blocks, d_packets, d_packet_bytes, stream);
         if (rc) return rc;
     }
     if (vbm_fe_launch_shift(&fe->f, fe->d_dec, st)) return VBM_EHIP;

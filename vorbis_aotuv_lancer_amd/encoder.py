@@ -134,6 +134,8 @@ class FrontEnd:
         self._h = C.c_void_p()
         check(lib.vbm_frontend_create(C.byref(self._h), encoder._h), "vbm_frontend_create")
         self._info = (PacketInfo * encoder.nstreams)()
+        # zero-copy record view of the info array: fields stream, block_mode, lW, W, nW, eos, granulepos, packetno
+        self._info_view = np.ctypeslib.as_array(self._info)
 
     def reset(self):
         check(lib.vbm_frontend_reset(self._h), "vbm_frontend_reset")
@@ -154,9 +156,18 @@ class FrontEnd:
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         check(lib.vbm_frontend_finish(self._h, ids.ctypes.data, len(ids), st), "vbm_frontend_finish")
 
+    @property
+    def max_buffered(self):
+        return lib.vbm_frontend_max_buffered(self._h)
+
+    @property
+    def capacity(self):
+        return lib.vbm_frontend_capacity(self._h)
+
     def encode_round(self, device=None):
-        """One blockout round over all streams.  Returns (info list, packets uint8 [n, max_bytes], nbytes int32
-        [n]) for the n blocks that came out (n may be 0: every stream needs more PCM)."""
+        """One blockout round over all streams.  Returns (info records, packets uint8 [n, max_bytes], nbytes int32
+        [n]) for the n blocks that came out (n may be 0: every stream needs more PCM).  The info records are a
+        numpy structured view (fields of vbm_packet_info) that the next round overwrites."""
         dev = device or torch.device("cuda", torch.cuda.current_device())
         S = self.enc.nstreams
         packets = torch.empty((S, self.enc.max_packet_bytes), dtype=torch.uint8, device=dev)
@@ -166,7 +177,7 @@ class FrontEnd:
         check(lib.vbm_frontend_encode_round(self._h, packets.data_ptr(), nbytes.data_ptr(), self._info, C.byref(n), st),
               "vbm_frontend_encode_round")
         k = n.value
-        return [self._info[i] for i in range(k)], packets[:k], nbytes[:k]
+        return self._info_view[:k], packets[:k], nbytes[:k]
 
     def close(self):
         if self._h:
