@@ -131,10 +131,11 @@ struct Geo {
 // first sample of block `blk`: rows of a block-major array, or (N == 128, envelope search) the
 // 128-sample window of search step first[stream] + t0 + t inside a channel's PCM buffer, blk =
 // channel * steps + t; nullptr when that step does not exist
+template <bool GATHER>
 __device__ __forceinline__ const float *block_src(const float *__restrict__ pcm, long blk, int n,
                                                   const vbm_ve_gather &g)
 {
-    if (!g.first) return pcm + blk * n;
+    if (!GATHER) return pcm + blk * n;
     const long c = blk / g.steps;
     const int t = (int)(blk - c * g.steps);
     const int s = (int)(c / g.ch);
@@ -144,7 +145,7 @@ __device__ __forceinline__ const float *block_src(const float *__restrict__ pcm,
 }
 
 // group of eight 16-B loads -> registers
-template <int N>
+template <int N, bool GATHER>
 __device__ __forceinline__ void issue_loads(float4 (&v)[8], const float *__restrict__ pcm,
                                             long group, long nblocks, int lane, const vbm_ve_gather &g)
 {
@@ -155,7 +156,7 @@ __device__ __forceinline__ void issue_loads(float4 (&v)[8], const float *__restr
         int b = P / G::C, p = P % G::C;
         int q0 = (p < G::R2) ? (G::R2 - 1 - p) : (7 * N / 16 - 1 - p);
         long blk = group * G::BPG + b;
-        const float *src = (blk < nblocks) ? block_src(pcm, blk, N, g) : nullptr;
+        const float *src = (blk < nblocks) ? block_src<GATHER>(pcm, blk, N, g) : nullptr;
         if (src)
             v[k] = *reinterpret_cast<const float4 *>(src + 4 * q0);
         else
@@ -163,7 +164,7 @@ __device__ __forceinline__ void issue_loads(float4 (&v)[8], const float *__restr
     }
 }
 
-template <int N>
+template <int N, bool GATHER = false>
 __global__ __launch_bounds__(64 * WAVES_PER_WG)
 void k_window_mdct(const float *__restrict__ pcm, float *__restrict__ out,
                    const uint8_t *__restrict__ wflags,  // per block: bit0 = lW, bit1 = nW (N == 2048 only; may be null = all long)
@@ -202,7 +203,7 @@ void k_window_mdct(const float *__restrict__ pcm, float *__restrict__ out,
     const float scale = 4.f / N;
 
     float4 v[8];
-    if (group < ngroups) issue_loads<N>(v, pcm, group, nblocks, lane, gather);
+    if (group < ngroups) issue_loads<N, GATHER>(v, pcm, group, nblocks, lane, gather);
 
     for (; group < ngroups; group += gstride) {
         // ---------------- window + odd-sample exchange -----------------------------
@@ -252,7 +253,7 @@ void k_window_mdct(const float *__restrict__ pcm, float *__restrict__ out,
             c[k].x = r1 * T.y + r0 * T.x;
             c[k].y = r1 * T.x - r0 * T.y;
         }
-        if (next < ngroups) issue_loads<N>(v, pcm, next, nblocks, lane, gather);
+        if (next < ngroups) issue_loads<N, GATHER>(v, pcm, next, nblocks, lane, gather);
         wave_lds_sync();  // exchange slots are reused below
 
         // ---------------- round A: index bits 8,7,6 (long blocks only) ----------------
@@ -439,7 +440,7 @@ extern "C" int vbm_launch_ve_mdct(const vbm_ve_gather *g, float *d_out, const fl
     long ngroups = (nblocks + 15) / 16;
     long wgs = (ngroups + WAVES_PER_WG - 1) / WAVES_PER_WG;
     if (wgs > 256 * 8) wgs = 256 * 8;
-    hipLaunchKernelGGL(k_window_mdct<128>, dim3((unsigned)wgs), dim3(64 * WAVES_PER_WG), 0, stream, g->pcm, d_out,
+    hipLaunchKernelGGL((k_window_mdct<128, true>), dim3((unsigned)wgs), dim3(64 * WAVES_PER_WG), 0, stream, g->pcm, d_out,
                        (const uint8_t *)nullptr, d_trig, d_win, (const float *)nullptr, 0, 2, nblocks, *g);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
