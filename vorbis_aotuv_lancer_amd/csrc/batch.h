@@ -73,6 +73,7 @@ struct vbm_batch {
     float *m6defT;                  // [partitions][coupling steps][Ls]  aoTuV M6 temp_def per partition (-1: none)
     int couple_parallel;            // coupling steps use disjoint channels: partitions may run sliced
     int couple_parts, couple_m6parts;  // partitions below the lowpass / those in the M6 range
+    int couple_fast;                // 0 general kernel; 1 lane-per-bin kernel, no coupling; 2 lane-per-bin, stereo one step
     int *vqlenT, *vqoffT;           // [stages][ch][max partvals][Ls]  bits / bit offset of every residue run
     uint64_t *vqcodeT;              // [stages][ch*n][64] per tile of `vq_slab_words` 8-byte words: code | len << 32
     size_t vq_slab_words;

@@ -332,6 +332,12 @@ static void configure(vbm_encoder *e, vbm_batch &b, int block_mode, int nsb, con
         int m6end = p.tonefix_end < lowpassr ? p.tonefix_end : lowpassr;
         b.couple_m6parts = m.coupling_steps ? (m6end + partition - 1) / partition : 0;
         if (b.couple_parts > b.n / 8 + 1) b.couple_parallel = 0;   // table rows were sized for partitions >= 8 bins
+        // lane-per-bin kernel (quant_kernels.hip, k_couple_fast): 32-bin partitions only
+        b.couple_fast = 0;
+        if (partition == 32 && p.normal_partition == 32 && (b.n % 32) == 0 && !getenv("VBM_COUPLE_GENERAL")) {
+            if (m.coupling_steps == 0) b.couple_fast = 1;
+            else if (m.coupling_steps == 1 && e->ch == 2 && b.couple_parallel) b.couple_fast = 2;
+        }
         b.pack_submaps = m.submaps;
         for (int i = 0; i < m.submaps && i < 16; i++) {
             const vbm_residue &r = s->residue[m.residuesubmap[i]];

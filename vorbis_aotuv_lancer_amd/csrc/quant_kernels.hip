@@ -494,11 +494,302 @@ __global__ void k_couple_quantize(vbm_batch b, int nchunks)
 #undef IW
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fast path for 32-bin partitions (long blocks): one LANE per (column, bin) instead of one lane per
+// stream-block with per-partition arrays in private memory.  A workgroup of 1024 threads owns 32
+// columns x one partition: rows are loaded / stored with the column index fastest (coalesced 128-B
+// row segments of the tiled arrays) and transposed through LDS so that the 32 lanes of a half-wave
+// hold the 32 bins of one column's partition in registers.
+//   MODE 0  no coupling: a column is a channel-block (any channel count, e.g. mono, 5.1 q8)
+//   MODE 1  stereo, one coupling step: a column is a stream-block, both channels in the lane
+// Per-bin work is elementwise.  The order-bound pieces of the source run as 32-step loops over the
+// half-wave with shuffles, in bin order: flag_lossless' running point1/point2 (:4597-4600), M6's
+// residue_def (:5018-5027).  noise_normalize's tail (sort + unit-norm promotion, :4800-4852) only
+// exists when normal_start falls inside the partition; then lane 0 of the half-wave runs the serial
+// routine above on LDS copies — the same code as the general kernel, so exact by construction.
+#define FP 32
+struct fast_consts {
+    int limit, sliding_lowpass, lowpassr, tonefix_end, n;
+    float prepoint, postpoint, prepoint_x, postpoint_x, prae;
+    nn_consts nn;
+};
+
+struct fast_lds {
+    float in_md[2][FP][FP + 1], in_ep[2][FP][FP + 1];
+    int in_iw[2][FP][FP + 1];
+    // serial fallback of noise_normalize: per half-wave arrays
+    float r[FP][FP], q[FP][FP], f[FP][FP], res[FP][FP];
+    int flag[FP][FP], out[FP][FP];
+};
+
+// per-channel part of a partition for this lane's bin (lib/psy.c:4952-4991)
+__device__ __forceinline__ void fast_channel(const fast_consts &c, fast_lds &L, const float *__restrict__ fromdB,
+                                             const int g, const int j, const int i, const int jn, const bool nz,
+                                             const float mdl, const float enp, const int iw, const float nepeak,
+                                             float &raw, float &quant, float &floor, float &res, int &flag, int &out)
+{
+    const int lane = threadIdx.x & 63, base = lane & 32;
+    if (!nz) {
+        floor = 1e-10f; raw = 0.f; quant = 0.f; res = 0.f; flag = 0; out = 0;
+        return;
+    }
+    floor = fromdB[iw];
+    // flag_lossless (lib/psy.c:4584-4624): point1/point2 advance by a constant per bin, in bin order
+    {
+        const int pointlimit = c.limit - i;
+        float point1, point2, ps1 = 0.f, ps2 = 0.f;
+        int ps = 0;
+        if (pointlimit > 0) {
+            point1 = c.prepoint;
+            point2 = c.prepoint_x;
+            if ((pointlimit - jn) <= 0) {
+                ps1 = (c.postpoint - c.prepoint) / jn;
+                ps2 = (c.postpoint_x - c.prepoint_x) / jn;
+                ps = 1;
+            }
+        } else {
+            point1 = c.postpoint;
+            point2 = c.postpoint_x;
+        }
+        if (ps) {
+            float p1 = point1, p2 = point2;
+            for (int t = 0; t < FP; t++) {
+                p1 += ps1;
+                p2 += ps2;
+                if (t == j) { point1 = p1; point2 = p2; }
+            }
+        }
+        res = mdl / floor;
+        const float r = fabsf(res);
+        point1 -= enp;
+        if (point1 < c.prepoint) point1 = c.prepoint;
+        if (r < point1) flag = (r < point2) ? 0 : -1;
+        else flag = 1;
+    }
+    quant = raw = mdl * mdl;
+    if (mdl < 0.f) raw *= -1.f;
+    floor *= floor;
+
+    // noise_normalize(p, limit, raw, quant, floor, res, NULL, ...) (lib/psy.c:4732-4854)
+    int start = (c.nn.normal_p ? c.nn.normal_start - i : jn);
+    if ((start > jn) || ((double)nepeak < -0.5)) start = jn;
+    if (start >= jn) {
+        out = (int)rint((double)res);
+    } else {
+        (void)base;
+        L.r[g][j] = raw; L.q[g][j] = quant; L.f[g][j] = floor; L.res[g][j] = res; L.out[g][j] = 0;
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        if (j == 0)
+            noise_normalize(&c.nn, c.limit, L.r[g], L.q[g], L.f[g], L.res[g], nullptr, 0.f, nepeak, i, jn, L.out[g], 1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        quant = L.q[g][j]; res = L.res[g][j]; out = L.out[g][j];
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(FP * FP) void k_couple_fast(vbm_batch b)
+{
+    __shared__ fast_lds L;
+    const vbm_setup *s = b.setup;
+    const vbm_psy *p = &s->psy[b.block_mode];
+    const vbm_map *vi = &s->map[b.W];
+    const int blobno = VBM_PACKETBLOBS / 2;
+    const size_t SW = b.slab_words;
+    const int NCH = (MODE == 1) ? 2 : 1;
+    fast_consts c;
+    c.n = p->n;
+    c.limit = s->coupling_pointlimit[p->blockflag][blobno];
+    c.prepoint = (float)s->stereo_threshholds[s->coupling_prepointamp[blobno]];
+    c.postpoint = (float)s->stereo_threshholds[s->coupling_postpointamp[blobno]];
+    c.prepoint_x = (float)s->stereo_threshholds_X[s->coupling_prepointamp[blobno]];
+    c.postpoint_x = (float)s->stereo_threshholds_X[s->coupling_postpointamp[blobno]];
+    if (c.prepoint_x < c.prepoint) c.prepoint_x = c.prepoint;
+    if (c.postpoint_x < c.prepoint) c.postpoint_x = c.prepoint;
+    c.sliding_lowpass = s->sliding_lowpass[b.W][blobno];
+    c.tonefix_end = p->tonefix_end;
+    c.prae = (vi->coupling_steps == 1) ? (float)0.34 : (float)0.825;
+    c.nn.normal_p = p->normal_p; c.nn.normal_start = p->normal_start; c.nn.normal_thresh = p->normal_thresh;
+    {
+        int lowpassr = s->block_lowpassr[b.W ? 1 : 0];
+        if (lowpassr % p->normal_partition) lowpassr = (lowpassr / p->normal_partition + 1) * p->normal_partition;
+        c.lowpassr = lowpassr;
+    }
+    const float *__restrict__ fromdB = s->fromdB;
+    const int ncols = (MODE == 1) ? b.nsb : b.ncb;
+    const int pi = blockIdx.y, i = pi * FP;
+    const int tid = threadIdx.x;
+
+    // ---- rows i..i+31 of the 32 columns of this workgroup: coalesced loads, LDS transpose -------
+    const int lr = tid >> 5, lc = tid & 31;
+    const int colL = blockIdx.x * FP + lc;
+    const bool past = (i >= c.lowpassr);   // partitions past the lowpass only zero the residue (lib/psy.c:5126-5131)
+    if (!past && colL < ncols && i + lr < c.n) {
+#pragma unroll
+        for (int k = 0; k < NCH; k++) {
+            const size_t cb = (MODE == 1) ? (size_t)colL * 2 + k : (size_t)colL;
+            const size_t a = (cb >> 6) * SW + (size_t)(i + lr) * 64 + (cb & 63);
+            L.in_md[k][lr][lc] = b.mdctT[a];
+            L.in_ep[k][lr][lc] = b.epeakT[a];
+            L.in_iw[k][lr][lc] = b.iworkT[a];
+        }
+    }
+    __syncthreads();
+
+    // ---- compute: lane = (column g, bin j) ---------------------------------------------------
+    const int g = tid >> 5, j = tid & 31;
+    const int col = blockIdx.x * FP + g;
+    const int lane = tid & 63, base = lane & 32;
+    const int jn = FP > c.n - i ? c.n - i : FP;
+    int out[2] = {0, 0};
+    if (!past && col < ncols) {
+        float raw[2], quant[2], floor[2], res[2];
+        int flag[2];
+        bool nz[2];
+        float npk[2];
+#pragma unroll
+        for (int k = 0; k < NCH; k++) {
+            const size_t cb = (MODE == 1) ? (size_t)col * 2 + k : (size_t)col;
+            nz[k] = b.nonzero[cb] != 0;
+            npk[k] = b.npeakT[(cb >> 6) * SW + (size_t)pi * 64 + (cb & 63)];
+            fast_channel(c, L, fromdB, g, j, i, jn, nz[k], L.in_md[k][j][g], L.in_ep[k][j][g], L.in_iw[k][j][g], npk[k],
+                         raw[k], quant[k], floor[k], res[k], flag[k], out[k]);
+        }
+
+        if (MODE == 1) {
+            const int Mi = vi->coupling_mag[0], Ai = vi->coupling_ang[0];
+            // registers of the magnitude / angle channel
+            float reM = raw[Mi & 1], reA = raw[Ai & 1], qeM = quant[Mi & 1], qeA = quant[Ai & 1];
+            float floorM = floor[Mi & 1], floorA = floor[Ai & 1], resM = res[Mi & 1], resA = res[Ai & 1];
+            int fM = flag[Mi & 1], fA = flag[Ai & 1], oM = out[Mi & 1], oA = out[Ai & 1];
+            float npM = npk[Mi & 1];
+            const float npA = npk[Ai & 1];
+            if (nz[0] || nz[1]) {
+                // M6 (lib/psy.c:5010-5051)
+                if (c.tonefix_end > i) {
+                    const bool cond = existe(resM, 0.5) || existe(resA, 0.5);
+                    const bool phase = refer_phase(reM, reA);
+                    const unsigned mc = (unsigned)(__ballot(cond && j < jn) >> base);
+                    const unsigned mp = (unsigned)(__ballot(cond && phase && j < jn) >> base);
+                    const int rp = __popc(mp), pp = __popc(mc & ~mp);
+                    const double term = fabs((double)fabsf(resM) - (double)fabsf(resA));
+                    float residue_def = 0;
+                    for (int t = 0; t < FP; t++) {
+                        const double tt = __shfl(term, base + t);
+                        if ((mc >> t) & 1u) residue_def = (float)((double)residue_def + tt);
+                    }
+                    const int ap = rp + pp;
+                    if (ap != 0) {
+                        const float temp_def = residue_def = residue_def / ap;
+                        const float *m6 = b.m6defT + (size_t)(col >> 6) * b.sb_slab_words + (col & 63);
+                        const float side = (pi > 0) ? m6[(size_t)(pi - 1) * 64] : -1.f;
+                        if (side > 0) residue_def = (float)((double)temp_def * 0.5 + (double)side * 0.5);
+                        if (residue_def > 1.f) {
+                            if (fM == -1 || fA == -1) fM = 1;
+                        }
+                        if ((float)rp / ap >= c.prae) {
+                            if ((fM == -1 || fA == -1) && refer_phase(reM, reA)) fM = 1;
+                        }
+                    }
+                }
+
+                bool lossy = false;
+                if (j < c.sliding_lowpass - i) {
+                    if (fM == 1 || fA == 1) {
+                        // lossless coupling
+                        reM = fabsf(reM) + fabsf(reA);
+                        qeM = qeM + qeA;
+                        fM = fA = 1;
+                        lossless_couplingf(&resM, &resA);
+                        lossless_coupling(&oM, &oA);
+                    } else {
+                        // lossy (point) coupling; one step: hpL .18, hpH .12 (lib/psy.c:5075-5081)
+                        if (j < c.limit - i) reM = min_indemnity_dipole_hypot(reM, reA, .18f);
+                        else reM = min_indemnity_dipole_hypot(reM, reA, .12f);
+                        qeM = fabsf(reM);
+                        reA = qeA = 0.f;
+                        fA = 1;
+                        oA = 0;
+                        resA = 0;
+                        lossy = true;
+                    }
+                }
+                floorM = floorA = floorM + floorA;
+                const unsigned ml = (unsigned)(__ballot(lossy && j < jn) >> base);
+                if (ml) {
+                    // NP(Mi) = -1 or min(NP(Mi), NP(Ai)) — idempotent, the source repeats it per lossy bin
+                    if (((double)npM < -0.5) || ((double)npA < -0.5)) npM = -1;
+                    else npM = VMIN(npM, npA);
+                    if (j == 0) {
+                        const size_t cbM = (size_t)col * 2 + Mi;
+                        b.npeakT[(cbM >> 6) * SW + (size_t)pi * 64 + (cbM & 63)] = npM;
+                    }
+                    // noise_normalize(p, limit, raw[Mi], quant[Mi], floor[Mi], res[Mi], flag[Mi], ...)
+                    int start = (c.nn.normal_p ? c.nn.normal_start - i : jn);
+                    if ((start > jn) || ((double)npM < -0.5)) start = jn;
+                    if (start >= jn) {
+                        if (fM != 1) {
+                            const float ve = (float)sqrt((double)(qeM / floorM));
+                            if (reM < 0) {
+                                oM = (int)-rint((double)ve);
+                                resM = -ve;
+                            } else {
+                                oM = (int)rint((double)ve);
+                                resM = ve;
+                            }
+                        }
+                    } else {
+                        L.r[g][j] = reM; L.q[g][j] = qeM; L.f[g][j] = floorM; L.res[g][j] = resM; L.flag[g][j] = fM;
+                        L.out[g][j] = oM;
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                        if (j == 0)
+                            noise_normalize(&c.nn, c.limit, L.r[g], L.q[g], L.f[g], L.res[g], L.flag[g], 0.f, npM, i, jn,
+                                            L.out[g], 1);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                        __builtin_amdgcn_wave_barrier();
+                        oM = L.out[g][j];
+                    }
+                }
+            }
+            out[Mi & 1] = oM;
+            out[Ai & 1] = oA;
+        }
+    }
+
+    // ---- store: back through LDS so that rows go out coalesced ---------------------------------
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NCH; k++) L.in_iw[k][j][g] = out[k];
+    __syncthreads();
+    if (colL < ncols && i + lr < c.n) {
+#pragma unroll
+        for (int k = 0; k < NCH; k++) {
+            const size_t cb = (MODE == 1) ? (size_t)colL * 2 + k : (size_t)colL;
+            b.iworkT[(cb >> 6) * SW + (size_t)(i + lr) * 64 + (cb & 63)] = L.in_iw[k][lr][lc];
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int vbm_launch_couple_quantize(const vbm_batch *b, hipStream_t st)
 {
     const unsigned tiles = (unsigned)((b->nsb + 63) / 64);
+    // fast path: 32-bin partitions with no coupling, or stereo with one coupling step
+    if (b->couple_fast == 1) {
+        hipLaunchKernelGGL(k_couple_fast<0>, dim3((unsigned)((b->ncb + FP - 1) / FP), (unsigned)(b->n / FP)), dim3(FP * FP), 0,
+                           st, *b);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
+    if (b->couple_fast == 2) {
+        if (b->couple_m6parts > 0)
+            hipLaunchKernelGGL(k_couple_m6stats, dim3(tiles, (unsigned)b->couple_m6parts), dim3(64), 0, st, *b);
+        hipLaunchKernelGGL(k_couple_fast<1>, dim3((unsigned)((b->nsb + FP - 1) / FP), (unsigned)(b->n / FP)), dim3(FP * FP), 0,
+                           st, *b);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     int nchunks = 1;
     if (b->couple_parallel) {
         if (b->couple_m6parts > 0)
