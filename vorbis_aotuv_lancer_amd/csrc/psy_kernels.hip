@@ -580,74 +580,66 @@ __global__ void k_tm_chase(vbm_batch b, int lpw)
     const int tn = p->total_octave_lines;
     const int linesper = p->eighth_octave_lines;
 
-    // seed_chase, lib/psy.c:773-934.  (a1,p1) is the stack top, (a2,p2) the entry below it.
+    // seed_chase, lib/psy.c:773-934.  (a1,p1) is the stack top, (a2,p2) the entry below it.  The source's
+    // nested tests collapse to one pop condition: an entry is popped while the stack holds two or more,
+    // the new seed is not below the top, and both top entries lie within `linesper` of i with the top
+    // not above the one below it; then the seed is pushed (stack < 2: pushed directly).
+    float *__restrict__ ampL = ampstack + tb;   // this lane's columns: element k at [k * 64]
+    int *__restrict__ posL = posstack + tb;
+    const int *__restrict__ seedL = seedk + tb;
     int stack = 0;
     float a1 = 0.f, a2 = 0.f;
     int p1 = 0, p2 = 0;
-#define TM_PUSH(ii, v)                                            \
-    {                                                             \
-        T(posstack, stack) = (ii);                                \
-        T(ampstack, stack) = (v);                                 \
-        stack++;                                                  \
-        a2 = a1; p2 = p1; a1 = (v); p1 = (ii);                    \
-    }
     for (int i = 0; i < tn; i += 8) {
         int kv[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) kv[u] = T(seedk, (i + u < tn) ? i + u : tn - 1);
+        for (int u = 0; u < 8; u++) kv[u] = seedL[(unsigned)((i + u < tn) ? i + u : tn - 1) << 6];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int ii = i + u;
             if (ii < tn) {
                 const float v = seed_val(kv[u]);
-                if (stack < 2) {
-                    TM_PUSH(ii, v)
-                } else {
-                    while (1) {
-                        if (v < a1) {
-                            TM_PUSH(ii, v)
-                            break;
-                        } else {
-                            if (ii < p1 + linesper) {
-                                if (stack > 1 && a1 <= a2 && ii < p2 + linesper) {
-                                    stack--;
-                                    a1 = a2; p1 = p2;
-                                    if (stack >= 2) {
-                                        a2 = T(ampstack, stack - 2);
-                                        p2 = T(posstack, stack - 2);
-                                    }
-                                    continue;
-                                }
-                            }
-                            TM_PUSH(ii, v)
-                            break;
-                        }
+                while (stack >= 2 && !(v < a1) && ii < p1 + linesper && a1 <= a2 && ii < p2 + linesper) {
+                    stack--;
+                    a1 = a2; p1 = p2;
+                    if (stack >= 2) {
+                        a2 = ampL[(unsigned)(stack - 2) << 6];
+                        p2 = posL[(unsigned)(stack - 2) << 6];
                     }
                 }
+                posL[(unsigned)stack << 6] = ii;
+                ampL[(unsigned)stack << 6] = v;
+                stack++;
+                a2 = a1; p2 = p1; a1 = v; p1 = ii;
             }
         }
     }
-#undef TM_PUSH
 
-    // the fill (lib/psy.c:1012-1026), walked by seed line so the stores stay row-coalesced: entry e
-    // covers lines up to endpos(e); entries whose endpos is already behind fill nothing
+    // the fill (lib/psy.c:1012-1026): entry e covers seed lines [pos, endpos(e)); the entry rows are the
+    // same for every lane, so eight entries are loaded ahead of the dependent walk
     {
-        int e = 0;
-        float amp = T(ampstack, 0), ampn = (stack > 1) ? T(ampstack, 1) : 0.f;
-        int endpos;
-        if (0 < stack - 1 && ampn > amp) endpos = T(posstack, 1);
-        else endpos = T(posstack, 0) + linesper + 1;
-        if (endpos > tn) endpos = tn;
-        for (int pos = 0; pos < tn; pos++) {
-            while (pos >= endpos && e + 1 < stack) {
-                e++;
-                amp = ampn;
-                ampn = (e < stack - 1) ? T(ampstack, e + 1) : 0.f;
-                if (e < stack - 1 && ampn > amp) endpos = T(posstack, e + 1);
-                else endpos = T(posstack, e) + linesper + 1;
-                if (endpos > tn) endpos = tn;
+        float *__restrict__ seedF = seed + tb;
+        int pos = 0;
+        for (int e0 = 0; e0 < stack; e0 += 8) {
+            float am[9];
+            int ps[9];
+#pragma unroll
+            for (int u = 0; u < 9; u++) {
+                const int e = (e0 + u < stack) ? e0 + u : stack - 1;
+                am[u] = ampL[(unsigned)e << 6];
+                ps[u] = posL[(unsigned)e << 6];
             }
-            T(seed, pos) = amp;
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int e = e0 + u;
+                if (e < stack) {
+                    int endpos;
+                    if (e < stack - 1 && am[u + 1] > am[u]) endpos = ps[u + 1];
+                    else endpos = ps[u] + linesper + 1;
+                    if (endpos > tn) endpos = tn;
+                    for (; pos < endpos; pos++) seedF[(unsigned)pos << 6] = am[u];
+                }
+            }
         }
     }
 }
