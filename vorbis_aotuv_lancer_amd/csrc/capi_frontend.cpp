@@ -90,8 +90,8 @@ extern "C" int vbm_frontend_create(vbm_frontend **out, vbm_encoder *enc)
     A(f.granulepos, long long, S); A(f.sequence, long long, S);
     A(f.ve_current, int, S); A(f.ve_cursor, int, S); A(f.ve_curmark, int, S); A(f.ve_stretch, int, S);
     A(f.ve_mark, int, (size_t)f.marks * S);
-    A(f.ve_ampbuf, float, (size_t)VBM_VE_BANDS * VBM_VE_AMP * SC);
-    A(f.ve_ampptr, int, (size_t)VBM_VE_BANDS * SC);
+    A(f.ve_ampbuf, float, (size_t)16 * VBM_VE_AMP * SC);
+    A(f.ve_ampptr, int, (size_t)16 * SC);
     A(f.ve_nearDC, float, (size_t)VBM_VE_NEARDC * SC);
     A(f.ve_nearacc, float, (size_t)2 * SC);
     A(f.ve_nearptr, int, SC);
@@ -135,8 +135,8 @@ extern "C" int vbm_frontend_reset(vbm_frontend *fe)
     zero(f.granulepos, S * sizeof(long long));
     zero(f.ve_current, S * sizeof(int)); zero(f.ve_stretch, S * sizeof(int));
     zero(f.ve_mark, (size_t)f.marks * S * sizeof(int));
-    zero(f.ve_ampbuf, (size_t)VBM_VE_BANDS * VBM_VE_AMP * SC * sizeof(float));
-    zero(f.ve_ampptr, (size_t)VBM_VE_BANDS * SC * sizeof(int));
+    zero(f.ve_ampbuf, (size_t)16 * VBM_VE_AMP * SC * sizeof(float));
+    zero(f.ve_ampptr, (size_t)16 * SC * sizeof(int));
     zero(f.ve_nearDC, (size_t)VBM_VE_NEARDC * SC * sizeof(float));
     zero(f.ve_nearacc, 2 * SC * sizeof(float));
     zero(f.ve_nearptr, SC * sizeof(int));

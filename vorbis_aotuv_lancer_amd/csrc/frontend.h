@@ -26,8 +26,8 @@ struct vbm_fe_state {
     // envelope_lookup (lib/envelope.h:56-76); SoA with the stream / channel index innermost
     int *ve_current, *ve_cursor, *ve_curmark, *ve_stretch;                 // [S]
     int *ve_mark;                // [marks][S]
-    float *ve_ampbuf;            // [VE_BANDS][VE_AMP][S*ch]
-    int *ve_ampptr;              // [VE_BANDS][S*ch]
+    float *ve_ampbuf;            // [VE_AMP][S*ch][16]  band innermost (12 used): the 16 lanes of a stream read one run
+    int *ve_ampptr;              // [S*ch][16]
     float *ve_nearDC;            // [VE_NEARDC][S*ch]
     float *ve_nearacc;           // [2][S*ch]   nearDC_acc, nearDC_partialacc
     int *ve_nearptr;             // [S*ch]

@@ -197,21 +197,32 @@ __device__ __forceinline__ float fe_todB(float x)
     return (float)((float)i * 7.17711438e-7f - 764.6161886f);
 }
 
-// steps [first + t0, min(last, first + t0 + CHUNK)) of every stream; 64 streams per wavefront
+// steps [first + t0, min(last, first + t0 + CHUNK)) of every stream.  Sixteen lanes per stream (four
+// streams per wavefront): lane jb < 12 owns band jb of the detector, lane 0 also the near-DC ring; the
+// 32 smoothed spectrum values of a (step, channel) are produced two per lane and shared through LDS.
+// The steps of a stream stay in order (ve->stretch couples them), channels and bands run side by side.
 __global__ __launch_bounds__(64) void k_fe_ve_filter(vbm_fe_state f, const vbm_setup *__restrict__ setup, int t0)
 {
-    __shared__ float s_vec[32][64];
-    const int s = blockIdx.x * 64 + threadIdx.x;
+    __shared__ float s_vec[4][32];
+    const int grp = threadIdx.x >> 4, jb = threadIdx.x & 15;
+    const int s = blockIdx.x * 4 + grp;
     if (s >= f.S) return;
-    const int l = threadIdx.x;
     const vbm_envelope *ve = &setup->ve;
-    const int SC = f.S * f.ch;
+    const long SC = (long)f.S * f.ch;
     const int first = f.ve_first[s] + t0, last = f.ve_last[s];
     if (first >= last) return;
     const float minV = ve->minenergy;
     const float stretch_penalty = ve->stretch_penalty;
     int ve_stretch = f.ve_stretch[s];
     const int S = f.S;
+    const bool band = jb < VBM_VE_BANDS;
+    // this lane's band constants
+    const int begin = band ? ve->band_begin[jb] : 0, end = band ? ve->band_end[jb] : 0;
+    const float total = band ? ve->band_total[jb] : 0.f;
+    const float pre_t = band ? ve->preecho_thresh[jb] : 0.f, post_t = band ? ve->postecho_thresh[jb] : 0.f;
+    float bw[VBM_VE_MAXBAND];
+#pragma unroll
+    for (int i = 0; i < VBM_VE_MAXBAND; i++) bw[i] = band ? ve->band_window[jb][i] : 0.f;
 
     for (int t = 0; t < VBM_FE_CHUNK; t++) {
         const int j = first + t;
@@ -229,14 +240,14 @@ __global__ __launch_bounds__(64) void k_fe_ve_filter(vbm_fe_state f, const vbm_s
         if (penalty > stretch_penalty) penalty = stretch_penalty;
 
         for (int ci = 0; ci < f.ch; ci++) {
-            const int c = s * f.ch + ci;
-            const float4 *spec = reinterpret_cast<const float4 *>(f.ve_spec + ((long)c * VBM_FE_CHUNK + t) * 64);
-            float decay;
+            const long c = (long)s * f.ch + ci;
+            const float *spec = f.ve_spec + (c * VBM_FE_CHUNK + t) * 64;
+            float decay = 0.f;
 
-            // near-DC spreading function (:127-148)
-            const float4 h0 = spec[0];
-            {
-                float temp = (float)((double)(h0.x * h0.x) + (.7 * (double)h0.y) * (double)h0.y + (.2 * (double)h0.z) * (double)h0.z);
+            // near-DC spreading function (:127-148), lane 0 of the group
+            if (jb == 0) {
+                const float h0 = spec[0], h1 = spec[1], h2 = spec[2];
+                float temp = (float)((double)(h0 * h0) + (.7 * (double)h1) * (double)h1 + (.2 * (double)h2) * (double)h2);
                 int ptr = f.ve_nearptr[c];
                 float acc = f.ve_nearacc[c], pacc = f.ve_nearacc[SC + c];
                 if (ptr == 0) {
@@ -250,83 +261,95 @@ __global__ __launch_bounds__(64) void k_fe_ve_filter(vbm_fe_state f, const vbm_s
                 f.ve_nearDC[(long)ptr * SC + c] = temp;
                 f.ve_nearacc[c] = acc;
                 f.ve_nearacc[SC + c] = pacc;
-
                 decay = (float)((double)decay * (1. / (VBM_VE_NEARDC + 1)));
                 ptr++;
                 if (ptr >= VBM_VE_NEARDC) ptr = 0;
                 f.ve_nearptr[c] = ptr;
                 decay = (float)((double)fe_todB(decay) * .5 - (double)15.f);
             }
+            decay = __shfl(decay, threadIdx.x & 48);   // from lane 0 of this 16-lane group
 
-            // spreading, limiting, spectrum smoothing (:151-159)
-#pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const float4 h = spec[q];
-                float val = h.x * h.x + h.y * h.y;
-                val = fe_todB(val) * .5f;
-                if (val < decay) val = decay;
-                if (val < minV) val = minV;
-                s_vec[2 * q][l] = val;
-                decay = (float)((double)decay - 8.);
-                val = h.z * h.z + h.w * h.w;
-                val = fe_todB(val) * .5f;
-                if (val < decay) val = decay;
-                if (val < minV) val = minV;
-                s_vec[2 * q + 1][l] = val;
-                decay = (float)((double)decay - 8.);
+            // spreading, limiting, spectrum smoothing (:151-159): value k uses decay after k subtractions of 8
+            // (subtracted one at a time, as the source rounds after each)
+            {
+                float dk = decay;
+                for (int k = 0; k < 32; k++) {
+                    if (k == jb || k == jb + 16) {
+                        const float a = spec[2 * k], bq = spec[2 * k + 1];
+                        float val = a * a + bq * bq;
+                        val = fe_todB(val) * .5f;
+                        if (val < dk) val = dk;
+                        if (val < minV) val = minV;
+                        s_vec[grp][k] = val;
+                    }
+                    dk = (float)((double)dk - 8.);
+                }
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
-            // preecho / postecho triggering by band (:162-559 scalar)
-            for (int jb = 0; jb < VBM_VE_BANDS; jb++) {
+            // preecho / postecho triggering by band (:162-559 scalar), one band per lane
+            if (band) {
                 float acc = 0.f;
-                const int begin = ve->band_begin[jb], end = ve->band_end[jb];
-                for (int i = 0; i < end; i++) acc += s_vec[i + begin][l] * ve->band_window[jb][i];
-                acc *= ve->band_total[jb];
+                for (int i = 0; i < end; i++) acc += s_vec[grp][i + begin] * bw[i];
+                acc *= total;
 
-                float *ampbuf = f.ve_ampbuf + (long)jb * VBM_VE_AMP * SC + c;   // element k at [k*SC]
-                const int cur = f.ve_ampptr[(long)jb * SC + c];
+                float *ampbuf = f.ve_ampbuf + c * 16 + jb;           // element k at [k * SC * 16]
+                const long kstride = SC * 16;
+                const int cur = f.ve_ampptr[c * 16 + jb];
                 float postmax, postmin, premax = -99999.f, premin = 99999.f;
                 int p = cur;
                 p--;
                 if (p < 0) p += VBM_VE_AMP;
                 {
-                    const float a = ampbuf[(long)p * SC];
+                    const float a = ampbuf[(long)p * kstride];
                     postmax = acc > a ? acc : a;
                     postmin = acc < a ? acc : a;
                 }
                 for (int i = 0; i < stretch; i++) {
                     p--;
                     if (p < 0) p += VBM_VE_AMP;
-                    const float a = ampbuf[(long)p * SC];
+                    const float a = ampbuf[(long)p * kstride];
                     premax = premax > a ? premax : a;
                     premin = premin < a ? premin : a;
                 }
                 const float valmin = postmin - premin;
                 const float valmax = postmax - premax;
 
-                ampbuf[(long)cur * SC] = acc;
+                ampbuf[(long)cur * kstride] = acc;
                 int np = cur + 1;
                 if (np >= VBM_VE_AMP) np = 0;
-                f.ve_ampptr[(long)jb * SC + c] = np;
+                f.ve_ampptr[c * 16 + jb] = np;
 
-                if (valmax > ve->preecho_thresh[jb] + penalty) ret |= 1 | 4;
-                if (valmin < ve->postecho_thresh[jb] - penalty) ret |= 2;
+                if (valmax > pre_t + penalty) ret |= 1 | 4;
+                if (valmin < post_t - penalty) ret |= 2;
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
+        // OR over the 16 lanes of the group
+        ret |= __shfl_xor(ret, 1);
+        ret |= __shfl_xor(ret, 2);
+        ret |= __shfl_xor(ret, 4);
+        ret |= __shfl_xor(ret, 8);
 
         // mark bookkeeping of _ve_envelope_search (lib/envelope.c:611-624)
-        f.ve_mark[(long)(j + VBM_VE_POST) * S + s] = 0;
-        if (ret & 1) {
-            f.ve_mark[(long)j * S + s] = 1;
-            f.ve_mark[(long)(j + 1) * S + s] = 1;
-        }
-        if (ret & 2) {
-            f.ve_mark[(long)j * S + s] = 1;
-            if (j > 0) f.ve_mark[(long)(j - 1) * S + s] = 1;
+        if (jb == 0) {
+            f.ve_mark[(long)(j + VBM_VE_POST) * S + s] = 0;
+            if (ret & 1) {
+                f.ve_mark[(long)j * S + s] = 1;
+                f.ve_mark[(long)(j + 1) * S + s] = 1;
+            }
+            if (ret & 2) {
+                f.ve_mark[(long)j * S + s] = 1;
+                if (j > 0) f.ve_mark[(long)(j - 1) * S + s] = 1;
+            }
         }
         if (ret & 4) ve_stretch = -1;
     }
-    f.ve_stretch[s] = ve_stretch;
+    if (jb == 0) f.ve_stretch[s] = ve_stretch;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -539,7 +562,7 @@ extern "C" int vbm_fe_launch_ve_range(const vbm_fe_state *f, hipStream_t st)
 
 extern "C" int vbm_fe_launch_ve_filter(const vbm_fe_state *f, const vbm_setup *d_setup, int t0, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_fe_ve_filter, dim3((unsigned)((f->S + 63) / 64)), dim3(64), 0, st, *f, d_setup, t0);
+    hipLaunchKernelGGL(k_fe_ve_filter, dim3((unsigned)((f->S + 3) / 4)), dim3(64), 0, st, *f, d_setup, t0);
     return CHECK_LAUNCH();
 }
 
