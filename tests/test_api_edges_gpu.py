@@ -1,0 +1,106 @@
+"""Edge cases of the C ABI on the device: argument errors follow the reference's conventions
+(OV_EINVAL = VBM_EINVAL, nothing is launched), empty batches are no-ops, digital silence takes the
+"floor unused" path (floor1_fit returns NULL, lib/floor1.c:641-644; one zero bit per channel,
+lib/floor1.c:969-972) exactly as in the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from tests import orc
+from tests.test_frontend_gpu import drain
+
+pytestmark = pytest.mark.gpu
+VBM_EINVAL = -131
+
+
+def test_analysis_batch_argument_errors(cuda):
+    import vorbis_aotuv_lancer_amd as v
+    from vorbis_aotuv_lancer_amd._lib import lib
+    enc = v.Encoder(v.Setup(2, 44100, 0.5), 8)
+    pcm = torch.zeros((4, 2, 2048), device=cuda)
+    pk = torch.empty((4, enc.max_packet_bytes), dtype=torch.uint8, device=cuda)
+    nb = torch.empty((4,), dtype=torch.int32, device=cuda)
+    ids = np.arange(4, dtype=np.int32)
+    fl = np.full(4, 3, np.uint8)
+
+    def call(mode=3, n=4, ids_=ids, pcm_ptr=None, pk_ptr=None):
+        return lib.vbm_analysis_batch(enc._h, mode, n, ids_.ctypes.data, fl.ctypes.data,
+                                      pcm.data_ptr() if pcm_ptr is None else pcm_ptr,
+                                      pk.data_ptr() if pk_ptr is None else pk_ptr, nb.data_ptr(), None)
+    assert call() == 0
+    assert call(mode=4) == VBM_EINVAL and call(mode=-1) == VBM_EINVAL
+    assert call(n=9) == VBM_EINVAL                                  # more blocks than the encoder was created for
+    assert call(n=0) == 0                                           # empty batch: no-op
+    assert call(ids_=np.array([0, 1, 2, 8], np.int32)) == VBM_EINVAL  # stream id out of range
+    assert call(pcm_ptr=pcm.data_ptr() + 4) == VBM_EINVAL           # PCM must be 16-byte aligned
+    assert call(pk_ptr=pk.data_ptr() + 1) == VBM_EINVAL             # packets must be 4-byte aligned
+    assert lib.vbm_analysis_batch(None, 3, 4, ids.ctypes.data, fl.ctypes.data, pcm.data_ptr(), pk.data_ptr(),
+                                  nb.data_ptr(), None) == VBM_EINVAL
+    with pytest.raises(ValueError):
+        enc.analysis_batch(3, ids, fl, pcm[:, :, :1024].contiguous())   # wrong block size for the block type
+
+
+def test_frontend_write_errors(cuda):
+    import vorbis_aotuv_lancer_amd as v
+    from vorbis_aotuv_lancer_amd._lib import lib
+    enc = v.Encoder(v.Setup(2, 44100, 0.5), 3)
+    fe = v.FrontEnd(enc)
+    chunk = torch.zeros((3, 2, 1024), device=cuda)
+    assert lib.vbm_frontend_write(fe._h, chunk.data_ptr(), 0, None) == VBM_EINVAL
+    assert lib.vbm_frontend_write(fe._h, chunk.data_ptr(), 5000, None) == VBM_EINVAL     # more than two long blocks at once
+    # without draining, the buffers fill up: the write that would overrun is refused (lib/block.c:540-541)
+    refused = False
+    for _ in range(16):
+        rc = lib.vbm_frontend_write(fe._h, chunk.data_ptr(), 1024, None)
+        if rc == VBM_EINVAL:
+            refused = True
+            break
+        assert rc == 0
+    assert refused and fe.max_buffered <= fe.capacity
+    got = [[] for _ in range(3)]
+    drain(fe, got)                                                   # draining makes room again
+    assert lib.vbm_frontend_write(fe._h, chunk.data_ptr(), 1024, None) == 0
+    drain(fe, got)
+    fe.finish()
+    assert lib.vbm_frontend_write(fe._h, chunk.data_ptr(), 1024, None) == VBM_EINVAL     # write after finish
+    assert lib.vbm_frontend_finish(fe._h, np.array([0], np.int32).ctypes.data, 1, None) == VBM_EINVAL   # finished twice
+
+
+@pytest.mark.parametrize("ch,rate,q", [(2, 44100, 0.5), (6, 48000, 0.8)])
+def test_digital_silence_and_near_silence(oracle, cuda, ch, rate, q):
+    """stream 0: exact zeros; stream 1: 1e-6 noise; stream 2: silence, then a click, then silence"""
+    import vorbis_aotuv_lancer_amd as v
+    n = 40 * 1024
+    rng = np.random.default_rng(3)
+    sigs = [np.zeros((ch, n), np.float32), (1e-6 * rng.standard_normal((ch, n))).astype(np.float32),
+            np.zeros((ch, n), np.float32)]
+    sigs[2][:, 20000:20003] = 0.9
+    osetup = orc.Setup(oracle, ch, rate, q)
+    want = []
+    for sig in sigs:
+        st = orc.Stream(osetup)
+        oracle.lib.orc_stream_set_capture(st.v, 0)
+        seq = []
+        for at in range(0, n, 1024):
+            st.write(sig[:, at:at + 1024])
+            seq.extend(st.blocks())
+        st.finish()
+        seq.extend(st.blocks())
+        st.close()
+        want.append([((b["lW"], b["W"], b["nW"], b["block_mode"], b["eos"], b["granulepos"], b["sequence"]), b["packet"])
+                     for b in seq])
+    enc = v.Encoder(v.Setup(ch, rate, q), 3)
+    fe = v.FrontEnd(enc)
+    got = [[] for _ in range(3)]
+    allp = torch.from_numpy(np.stack(sigs)).to(cuda)
+    for at in range(0, n, 1024):
+        fe.write(allp[:, :, at:at + 1024].contiguous())
+        drain(fe, got)
+    fe.finish()
+    drain(fe, got)
+    for s in range(3):
+        assert got[s] == want[s], f"stream {s} differs from the oracle"
+    # exact zeros: every channel's floor is unused -> 1 type bit + mode/window bits + one 0 bit per channel
+    assert max(len(p) for _, p in got[0]) <= 2

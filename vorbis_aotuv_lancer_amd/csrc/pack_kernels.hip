@@ -6,9 +6,9 @@
 //                   (lib/floor1.c:856-942); nonzero[] propagation over the coupling steps
 //                   (lib/psy.c:5133-5140); block-state update :1297-1305.  Serial, short.
 //   per residue submap (lib/mapping0.c:1273-1295):
-//   k_res_class     res*_class (_01class lib/res0.c:406-468, _2class :473-526) and the res2
-//                   interleave (:781-787), sliced over partitions
-//   k_res_vq        the cascade of _01forward (:528-640): _encodepart :384-404 ->
+//   k_res_vq        res*_class (_01class lib/res0.c:406-468, _2class :473-526) and the res2
+//                   interleave (:781-787) of its partition slice, then
+//                   the cascade of _01forward (:528-640): _encodepart :384-404 ->
 //                   local_book_besterror :316-378.  A partition's stages only touch that
 //                   partition's samples, so partitions are sliced over blockIdx.y; every codeword
 //                   goes to a scratch slot (code | length << 32) and the partition's bit count per
@@ -294,16 +294,10 @@ __global__ void k_pack_head(vbm_batch b)
     }
 }
 
-__global__ void k_res_class(vbm_batch b, int sm, int nchunks)
+// classification of partitions [i0, i1) of one stream-block (res*_class) + the res2 interleave
+__device__ __forceinline__ void res_classify(const vbm_batch &b, const res_view &v, const int sb, const size_t col0, const int i0, const int i1)
 {
-    const int sb = blockIdx.x * blockDim.x + threadIdx.x;
-    if (sb >= b.nsb) return;
-    const vbm_map *info = &b.setup->map[b.W];
-    const size_t col0 = (size_t)sb * b.ch;
-    const res_view v = residue_view(b, info, sm, col0);
-    if (!v.used) return;
     const vbm_residue *r = v.r;
-    const int i0 = (int)((long)v.partvals * blockIdx.y / nchunks), i1 = (int)((long)v.partvals * (blockIdx.y + 1) / nchunks);
     int *partword = b.partwordT + SBT(sb);
     const int possible_partitions = r->partitions;
     const int rbegin = r->begin;
@@ -365,6 +359,8 @@ __global__ void k_res_vq(vbm_batch b, int sm, int nchunks)
     if (!v.used) return;
     const vbm_residue *r = v.r;
     const int i0 = (int)((long)v.partvals * blockIdx.y / nchunks), i1 = (int)((long)v.partvals * (blockIdx.y + 1) / nchunks);
+    // this slice's classes first (the same lane reads them back below)
+    res_classify(b, v, sb, col0, i0, i1);
     const int *partword = b.partwordT + SBT(sb);
     int *lenT = b.vqlenT + SBT(sb);
     uint64_t *slot = b.vqcodeT + (size_t)(sb >> 6) * b.vq_slab_words + (sb & 63);
@@ -519,7 +515,6 @@ extern "C" int vbm_launch_pack(const vbm_batch *b, hipStream_t st)
     for (int sm = 0; sm < b->pack_submaps; sm++) {
         int nchunks = b->pack_partvals[sm] < 32 ? b->pack_partvals[sm] : 32;
         if (nchunks < 1) nchunks = 1;
-        hipLaunchKernelGGL(k_res_class, dim3(tiles, (unsigned)nchunks), dim3(64), 0, st, *b, sm, nchunks);
         hipLaunchKernelGGL(k_res_vq, dim3(tiles, (unsigned)nchunks), dim3(64), 0, st, *b, sm, nchunks);
         hipLaunchKernelGGL(k_res_offsets, dim3(tiles), dim3(64), 0, st, *b, sm);
         hipLaunchKernelGGL(k_res_emit, dim3(tiles, (unsigned)nchunks), dim3(64), 0, st, *b, sm, nchunks);
