@@ -558,10 +558,20 @@ __global__ void k_tm_stamp(vbm_batch b, int nchunks)
             const float *curve = posts + 2;
             const int post1 = (int)posts[1];
             int seedptr = (int)((float)ocl + (posts[0] - VBM_EHMER_OFFSET) * linesper - (linesper >> 1));
-            for (int i = (int)posts[0]; i < post1; i++) {
-                if (seedptr > 0) atomicMax(&T(seed, seedptr), seed_key(max + curve[i]));
-                seedptr += linesper;
-                if (seedptr >= tn) break;
+            // the curve values are loaded eight at a time ahead of the stamps (measured: issuing the eight
+            // atomics without branches, with no-op stamps for the missing points, is slower — the stamps are
+            // bound by atomic throughput, not by the waits the compiler puts between them)
+            for (int i = (int)posts[0]; i < post1 && seedptr < tn; i += 8) {
+                float cv[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) cv[u] = curve[(i + u < post1) ? i + u : post1 - 1];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    if (i + u < post1 && seedptr < tn) {
+                        if (seedptr > 0) atomicMax(&T(seed, seedptr), seed_key(max + cv[u]));
+                        seedptr += linesper;
+                    }
+                }
             }
         }
     }
@@ -587,9 +597,15 @@ __global__ void k_tm_chase(vbm_batch b, int lpw)
     float *__restrict__ ampL = ampstack + tb;   // this lane's columns: element k at [k * 64]
     int *__restrict__ posL = posstack + tb;
     const int *__restrict__ seedL = seedk + tb;
-    int stack = 0;
-    float a1 = 0.f, a2 = 0.f;
-    int p1 = 0, p2 = 0;
+    // The top TM_K stack entries live in registers (ra[0], rp[0] = top); a push shifts them down (the
+    // entry falling out is in memory already), a pop shifts them up.  Memory is only read when a run of
+    // pops has used up the register copies: then the next TM_K - 1 levels are fetched together.
+#define TM_K 8
+    int stack = 0, nreg = 0;
+    float ra[TM_K];
+    int rp[TM_K];
+#pragma unroll
+    for (int k = 0; k < TM_K; k++) { ra[k] = 0.f; rp[k] = 0; }
     for (int i = 0; i < tn; i += 8) {
         int kv[8];
 #pragma unroll
@@ -599,21 +615,35 @@ __global__ void k_tm_chase(vbm_batch b, int lpw)
             const int ii = i + u;
             if (ii < tn) {
                 const float v = seed_val(kv[u]);
-                while (stack >= 2 && !(v < a1) && ii < p1 + linesper && a1 <= a2 && ii < p2 + linesper) {
+                while (stack >= 2 && !(v < ra[0]) && ii < rp[0] + linesper && ra[0] <= ra[1] && ii < rp[1] + linesper) {
                     stack--;
-                    a1 = a2; p1 = p2;
-                    if (stack >= 2) {
-                        a2 = ampL[(unsigned)(stack - 2) << 6];
-                        p2 = posL[(unsigned)(stack - 2) << 6];
+                    nreg--;
+#pragma unroll
+                    for (int k = 0; k < TM_K - 1; k++) { ra[k] = ra[k + 1]; rp[k] = rp[k + 1]; }
+                    if (nreg < 2 && stack >= 2) {
+                        // registers hold level 0 only: fetch levels 1 .. TM_K-1 (entries stack-2, stack-3, ...)
+#pragma unroll
+                        for (int k = 1; k < TM_K; k++) {
+                            const int e = stack - 1 - k;
+                            if (e >= 0) {
+                                ra[k] = ampL[(unsigned)e << 6];
+                                rp[k] = posL[(unsigned)e << 6];
+                            }
+                        }
+                        nreg = stack < TM_K ? stack : TM_K;
                     }
                 }
                 posL[(unsigned)stack << 6] = ii;
                 ampL[(unsigned)stack << 6] = v;
                 stack++;
-                a2 = a1; p2 = p1; a1 = v; p1 = ii;
+#pragma unroll
+                for (int k = TM_K - 1; k > 0; k--) { ra[k] = ra[k - 1]; rp[k] = rp[k - 1]; }
+                ra[0] = v; rp[0] = ii;
+                if (nreg < TM_K) nreg++;
             }
         }
     }
+#undef TM_K
 
     // the fill (lib/psy.c:1012-1026): entry e covers seed lines [pos, endpos(e)); the entry rows are the
     // same for every lane, so eight entries are loaded ahead of the dependent walk
