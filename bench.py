@@ -37,6 +37,7 @@ QUALITY = 0.5
 N_LONG = 2048
 HOP = N_LONG // 2
 SPLIT = int(os.environ.get("VBM_BENCH_SPLIT", "1"))   # sub-batches per step, one HIP stream each
+TWO_STREAMS = os.environ.get("VBM_BENCH_TWO_STREAMS", "1") != "0"   # vbm_analysis_batch2: front / back half streams
 MAX_ROUNDS = int(os.environ.get("VBM_BENCH_MAX_ROUNDS", "2"))   # --from-pcm: blockout rounds per write
 DISTINCT_STEPS = 8              # PCM for this many consecutive blocks per stream is kept in HBM
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -135,6 +136,9 @@ def main():
     wflags = np.full(per, 3, dtype=np.uint8)   # lW = nW = long
     parts = [[blk[p * per:(p + 1) * per] for blk in blocks] for p in range(SPLIT)]   # contiguous views
 
+    back_queues = [torch.cuda.Stream(device=dev) for _ in range(SPLIT)]
+    outs = [[(torch.empty((per, enc.max_packet_bytes), dtype=torch.uint8, device=dev),
+              torch.empty((per,), dtype=torch.int32, device=dev)) for _ in range(2)] for _ in range(SPLIT)]
     fe = None
     if args.from_pcm:
         # one continuous signal per stream, cut into 1024-sample writes (23.2 ms of audio per step)
@@ -186,7 +190,11 @@ def main():
         out = None
         for p in range(SPLIT):
             with torch.cuda.stream(queues[p]):
-                out = encs[p].analysis_batch(LONG, ids, wflags, parts[p][k % DISTINCT_STEPS])
+                if TWO_STREAMS:   # back half of this step beside the front half of the next (vbm_analysis_batch2)
+                    out = encs[p].analysis_batch(LONG, ids, wflags, parts[p][k % DISTINCT_STEPS],
+                                                 back_stream=back_queues[p], out=outs[p][k & 1])
+                else:
+                    out = encs[p].analysis_batch(LONG, ids, wflags, parts[p][k % DISTINCT_STEPS])
         return out
 
     def barrier():
@@ -274,8 +282,10 @@ def main():
                                     "not in the timed region (long blocks only; --from-pcm times the stream front "
                                     "end as well)"),
                 "mean_packet_bytes": mean_bytes,
-                "parallelism": f"stream-shard x{world} (no collective); {SPLIT} sub-batch(es) of {per} streams per "
-                               "step on separate HIP streams",
+                "parallelism": f"stream-shard x{world} (no collective); "
+                               + ("front half (transforms, psychoacoustics) and back half (floor, couple/quantise, "
+                                  "packets) of consecutive steps on two HIP streams (vbm_analysis_batch2)"
+                                  if TWO_STREAMS and not args.from_pcm else "one HIP stream"),
             },
             "roofline": r_dom,
             "mdct_roofline": r_mdct,

@@ -136,6 +136,19 @@ int vbm_encoder_max_packet_bytes(const vbm_encoder *enc);
 int vbm_analysis_batch(vbm_encoder *enc, int block_mode, int nsb, const int *stream_ids,
                        const uint8_t *wflags, const float *d_pcm, uint8_t *d_packets,
                        int *d_packet_bytes, void *stream);
+/* Two-stream form of vbm_analysis_batch.  The FRONT half of the path (window, MDCT, FFT,
+ * psychoacoustics, _vp_offset_and_mix: every kernel that reads or writes the carried per-stream
+ * state) is ordered on `stream_front`, the BACK half (floor1_fit/_encode,
+ * _vp_couple_quantize_normalize, residue VQ, packet assembly) on `stream_back`; d_pcm must be ready
+ * on stream_front, packets are ready on stream_back.  Consecutive calls use alternate workspaces,
+ * so with two different streams the back half of one call runs while the front half of the next
+ * one does: the back half's few-wavefront kernels (floor fit) and the front half's wide ones
+ * share the GPU.  Results are those of vbm_analysis_batch.  stream_back == stream_front is
+ * vbm_analysis_batch. */
+int vbm_analysis_batch2(vbm_encoder *enc, int block_mode, int nsb, const int *stream_ids,
+                        const uint8_t *wflags, const float *d_pcm, uint8_t *d_packets,
+                        int *d_packet_bytes, void *stream_front, void *stream_back);
+
 /* One ROUND: blocks of all four block types at once (what one pass of vorbis_analysis_blockout over
  * all streams yields).  counts[m] blocks of type m; stream_ids / wflags (host) grouped by type, type
  * 0 first; d_pcm: the blocks of type m start at float offset (number of blocks of lower types) *

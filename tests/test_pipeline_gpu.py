@@ -28,7 +28,8 @@ def oracle_blocks(oracle, ch, rate, q, seconds, seed):
     return out
 
 
-def run_case(oracle, cuda, ch, rate, q, nstreams, seconds, check_stages=True, res1_channels=(), sub_batches=1):
+def run_case(oracle, cuda, ch, rate, q, nstreams, seconds, check_stages=True, res1_channels=(), sub_batches=1,
+             two_streams=False):
     import vorbis_aotuv_lancer_amd as v
     streams = [oracle_blocks(oracle, ch, rate, q, seconds, seed=100 + s) for s in range(nstreams)]
     nsteps = min(len(b) for b in streams)
@@ -39,6 +40,8 @@ def run_case(oracle, cuda, ch, rate, q, nstreams, seconds, check_stages=True, re
     assert enc.sub_batches == sub_batches
     seen_modes = set()
     mismatches = []
+    pending = []
+    back = torch.cuda.Stream(device=cuda) if two_streams else None
     for k in range(nsteps):
         by_mode = {}
         for s in range(nstreams):
@@ -48,6 +51,12 @@ def run_case(oracle, cuda, ch, rate, q, nstreams, seconds, check_stages=True, re
             blks = [streams[s][k] for s in ids]
             pcm = torch.from_numpy(np.stack([b["pcm"] for b in blks])).to(cuda)
             wflags = [b["lW"] | (b["nW"] << 1) for b in blks]
+            if two_streams:   # vbm_analysis_batch2: back half on its own stream; no host sync between the calls
+                outs = (torch.empty((len(ids), enc.max_packet_bytes), dtype=torch.uint8, device=cuda),
+                        torch.empty((len(ids),), dtype=torch.int32, device=cuda))
+                pending.append((k, mode, blks, outs))
+                enc.analysis_batch(mode, ids, wflags, pcm, back_stream=back, out=outs)
+                continue
             packets, nbytes = enc.analysis_batch(mode, ids, wflags, pcm)
             nbytes = nbytes.cpu().numpy()
             packets = packets.cpu().numpy()
@@ -80,6 +89,15 @@ def run_case(oracle, cuda, ch, rate, q, nstreams, seconds, check_stages=True, re
                 if nbytes[i] != len(b["packet"]) or pk != b["packet"]:
                     mismatches.append((k, mode, "packet", (ids[i], int(nbytes[i]), len(b["packet"]))))
             assert not mismatches, mismatches[:8]
+    if two_streams:
+        torch.cuda.synchronize()
+        for k, mode, blks, (packets, nbytes) in pending:
+            packets, nbytes = packets.cpu().numpy(), nbytes.cpu().numpy()
+            for i, b in enumerate(blks):
+                pk = bytes(packets[i, :max(nbytes[i], 0)])
+                if nbytes[i] != len(b["packet"]) or pk != b["packet"]:
+                    mismatches.append((k, mode, "packet", (i, int(nbytes[i]), len(b["packet"]))))
+        assert not mismatches, mismatches[:8]
     enc.close()
     setup.close()
     return seen_modes, nsteps
@@ -104,3 +122,10 @@ def test_stereo_q5_many_streams_in_sub_batches(oracle, cuda):
     """150 streams = 3 tiles of 64 stream-blocks, encoded as 2 slices on separate internal HIP streams
     (vbm_encoder_set_sub_batches): packets must still equal the oracle's for every stream."""
     run_case(oracle, cuda, 2, 44100, 0.5, nstreams=150, seconds=0.7, check_stages=False, sub_batches=2)
+
+
+def test_stereo_q5_two_stream_form(oracle, cuda):
+    """vbm_analysis_batch2: back half (floor, couple/quantise, packets) of every call on a second stream,
+    overlapping the front half of the next call, no host synchronisation in between; all block types."""
+    modes, _ = run_case(oracle, cuda, 2, 44100, 0.5, nstreams=20, seconds=3.0, check_stages=False, two_streams=True)
+    assert modes == {0, 1, 2, 3}

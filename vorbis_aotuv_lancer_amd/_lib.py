@@ -45,6 +45,8 @@ SIGNATURES = {
     "vbm_encoder_max_packet_bytes": (C.c_int, [C.c_void_p]),
     "vbm_analysis_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p]),
+    "vbm_analysis_batch2": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p]),
     "vbm_analysis_round": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p]),
     "vbm_encoder_fetch": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_char),

@@ -30,9 +30,17 @@ struct vbm_encoder {
     int max_packet_bytes;
     int max_oct, max_partvals;
     std::vector<void *> allocs;
-    vbm_batch b;             // template with all workspace pointers set (device pointers)
-    int *d_stream_id;
-    uint8_t *d_wflags;
+    // Two complete batch workspaces (device pointers; the stream state is shared).  Consecutive calls
+    // alternate between them, so that vbm_analysis_batch2 can run the second half of call k (floor fit,
+    // couple/quantise, packet assembly) on one HIP stream while the first half of call k+1 (transforms,
+    // psychoacoustics — everything that touches the carried stream state) runs on another.
+    vbm_batch bw[2];
+    int *d_stream_id[2];
+    uint8_t *d_wflags[2];
+    int cur = 0;             // workspace of the last call (vbm_encoder_fetch)
+    int next = 0;            // workspace of the next call
+    hipEvent_t ev_front[2] = {nullptr, nullptr}, ev_back[2] = {nullptr, nullptr};
+    bool back_pending[2] = {false, false};
     // last batch (for vbm_encoder_fetch)
     int last_nsb, last_mode;
     // sub-batches: the stages after the transforms run as `nsplit` tile-aligned slices of the batch,
@@ -47,8 +55,8 @@ struct vbm_encoder {
     uint8_t *h_flags[2] = {nullptr, nullptr};
     hipEvent_t ev_stage[2] = {nullptr, nullptr};
     int stage_turn = 0;
-    std::vector<int> last_ids;
-    std::vector<uint8_t> last_flags;
+    std::vector<int> last_ids[2];
+    std::vector<uint8_t> last_flags[2];
     // optional per-stage timing (HIP events on the stream each kernel is launched on)
     bool profiling = false;
     std::vector<hipEvent_t> events;   // pool; a (begin, end) pair per recorded stage launch
@@ -96,6 +104,10 @@ extern "C" void vbm_encoder_destroy(vbm_encoder *e)
     for (hipEvent_t ev : e->ev_aux_join) (void)hipEventDestroy(ev);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     for (int i = 0; i < 2; i++) {
+        if (e->ev_front[i]) (void)hipEventDestroy(e->ev_front[i]);
+        if (e->ev_back[i]) (void)hipEventDestroy(e->ev_back[i]);
+    }
+    for (int i = 0; i < 2; i++) {
         if (e->h_ids[i]) (void)hipHostFree(e->h_ids[i]);
         if (e->h_flags[i]) (void)hipHostFree(e->h_flags[i]);
         if (e->ev_stage[i]) (void)hipEventDestroy(e->ev_stage[i]);
@@ -141,8 +153,9 @@ extern "C" int vbm_encoder_create(vbm_encoder **out, vbm_setup_handle *setup, in
 
     const int Nmax = s->blocksizes[1], nmax = Nmax / 2;
     const size_t L = e->L, Ls = e->Ls;
-    vbm_batch &b = e->b;
-    memset(&b, 0, sizeof(b));
+    memset(e->bw, 0, sizeof(e->bw));
+  {
+    vbm_batch &b = e->bw[0];
     b.setup = vbm_setup_device(e->H);
     b.ch = e->ch;
     b.max_packet_bytes = e->max_packet_bytes;
@@ -165,8 +178,18 @@ extern "C" int vbm_encoder_create(vbm_encoder **out, vbm_setup_handle *setup, in
         (void)hipMemcpy(b.st.g_ampmax, init.data(), nstreams * sizeof(float), hipMemcpyHostToDevice);
         (void)hipMemcpy(b.st.vbi_ampmax, init.data(), nstreams * sizeof(float), hipMemcpyHostToDevice);
     }
-    A(e->d_stream_id, int, Ls);
-    A(e->d_wflags, uint8_t, Ls);
+  }
+  for (int w = 0; w < 2; w++) {
+    vbm_batch &b = e->bw[w];
+    if (w) {
+        memset(&b, 0, sizeof(b));
+        b.setup = e->bw[0].setup;
+        b.ch = e->ch;
+        b.max_packet_bytes = e->max_packet_bytes;
+        b.st = e->bw[0].st;
+    }
+    A(e->d_stream_id[w], int, Ls);
+    A(e->d_wflags[w], uint8_t, Ls);
     A(b.mdct_bm, float, L * nmax);
     A(b.logfft_bm, float, L * nmax);
     A(b.qf_bm, uint16_t, L * nmax);
@@ -221,9 +244,16 @@ extern "C" int vbm_encoder_create(vbm_encoder **out, vbm_setup_handle *setup, in
     A(b.packetT, uint8_t, Ls * (size_t)e->max_packet_bytes);   // [sb>>6][max_packet_bytes][64]
     A(b.packet_bytes, int, Ls);
     A(b.packet_bits, int, Ls);
+    b.stream_id = e->d_stream_id[w];
+    b.wflags = e->d_wflags[w];
+  }
 #undef A
-    b.stream_id = e->d_stream_id;
-    b.wflags = e->d_wflags;
+    for (int i = 0; i < 2; i++)
+        if (hipEventCreateWithFlags(&e->ev_front[i], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&e->ev_back[i], hipEventDisableTiming) != hipSuccess) {
+            vbm_encoder_destroy(e);
+            return VBM_EHIP;
+        }
     for (int i = 0; i < 2; i++) {
         if (hipHostMalloc((void **)&e->h_ids[i], Ls * sizeof(int), hipHostMallocDefault) != hipSuccess ||
             hipHostMalloc((void **)&e->h_flags[i], Ls, hipHostMallocDefault) != hipSuccess ||
@@ -288,7 +318,7 @@ extern "C" int vbm_encoder_max_packet_bytes(const vbm_encoder *e) { return e ? e
 extern "C" int vbm_encoder_reset(vbm_encoder *e)
 {
     if (!e) return VBM_EINVAL;
-    vbm_stream_state &st = e->b.st;
+    vbm_stream_state &st = e->bw[0].st;
     (void)hipMemset(st.mblock, 0, (size_t)(st.Lc / 64) * st.slab_words * sizeof(float));   // mblock + tblock
     (void)hipMemset(st.lowcomp, 0, (size_t)st.Lc * sizeof(float));
     (void)hipMemset(st.lW_block_mode, 0, e->S * sizeof(int));
@@ -300,9 +330,9 @@ extern "C" int vbm_encoder_reset(vbm_encoder *e)
     return VBM_OK;
 }
 
-static void configure(vbm_encoder *e, vbm_batch &b, int block_mode, int nsb, const float *d_pcm)
+static void configure(vbm_encoder *e, vbm_batch &b, int block_mode, int nsb, const float *d_pcm, int w)
 {
-    b = e->b;
+    b = e->bw[w];
     const vbm_setup *s = e->hs;
     b.block_mode = block_mode;
     b.W = block_mode >> 1;
@@ -375,6 +405,18 @@ extern "C" int vbm_analysis_batch(vbm_encoder *e, int block_mode, int nsb, const
                                   const uint8_t *wflags, const float *d_pcm, uint8_t *d_packets,
                                   int *d_packet_bytes, void *stream)
 {
+    return vbm_analysis_batch2(e, block_mode, nsb, stream_ids, wflags, d_pcm, d_packets, d_packet_bytes, stream, stream);
+}
+
+// Two-stream form: the FRONT half (transforms, psychoacoustics, offset_and_mix — every kernel that reads or
+// writes the carried stream state) is ordered on `stream_front`, the BACK half (floor fit/encode,
+// couple/quantise, packet assembly) on `stream_back`.  With two different streams the back half of one
+// call overlaps the front half of the next (consecutive calls use alternate workspaces).
+extern "C" int vbm_analysis_batch2(vbm_encoder *e, int block_mode, int nsb, const int *stream_ids,
+                                   const uint8_t *wflags, const float *d_pcm, uint8_t *d_packets,
+                                   int *d_packet_bytes, void *stream_front, void *stream_back)
+{
+    void *stream = stream_front;
     if (!e || block_mode < 0 || block_mode > 3 || nsb < 0 || nsb > e->cap) return VBM_EINVAL;
     if (nsb == 0) return VBM_OK;
     if (!stream_ids || !wflags || !d_pcm) return VBM_EINVAL;
@@ -384,34 +426,44 @@ extern "C" int vbm_analysis_batch(vbm_encoder *e, int block_mode, int nsb, const
     for (int i = 0; i < nsb; i++)
         if (stream_ids[i] < 0 || stream_ids[i] >= e->S) return VBM_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    hipStream_t sback = (hipStream_t)stream_back;
+    const bool two = (sback != st);
     hipError_t err;
+    const int w = e->next;
+    e->next ^= 1;
+    e->cur = w;
+    // this workspace was last read by the back half of the call before the previous one
+    if (e->back_pending[w]) {
+        if ((err = hipStreamWaitEvent(st, e->ev_back[w], 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
+        e->back_pending[w] = false;
+    }
     // stream ids / window flags: through pinned staging so the copy never stalls the host, and not
     // at all when the caller repeats the previous lists (the steady state of a streaming encode)
-    if ((int)e->last_ids.size() != nsb || memcmp(e->last_ids.data(), stream_ids, nsb * sizeof(int)) ||
-        memcmp(e->last_flags.data(), wflags, nsb)) {
+    if ((int)e->last_ids[w].size() != nsb || memcmp(e->last_ids[w].data(), stream_ids, nsb * sizeof(int)) ||
+        memcmp(e->last_flags[w].data(), wflags, nsb)) {
         const int t = e->stage_turn;
         e->stage_turn ^= 1;
         (void)hipEventSynchronize(e->ev_stage[t]);   // the copy that last used this buffer has run
         memcpy(e->h_ids[t], stream_ids, nsb * sizeof(int));
         memcpy(e->h_flags[t], wflags, nsb);
-        if ((err = hipMemcpyAsync(e->d_stream_id, e->h_ids[t], nsb * sizeof(int), hipMemcpyHostToDevice, st)) != hipSuccess)
+        if ((err = hipMemcpyAsync(e->d_stream_id[w], e->h_ids[t], nsb * sizeof(int), hipMemcpyHostToDevice, st)) != hipSuccess)
             return vbm_set_hip_error(err, "hipMemcpyAsync(stream_ids)");
-        if ((err = hipMemcpyAsync(e->d_wflags, e->h_flags[t], nsb, hipMemcpyHostToDevice, st)) != hipSuccess)
+        if ((err = hipMemcpyAsync(e->d_wflags[w], e->h_flags[t], nsb, hipMemcpyHostToDevice, st)) != hipSuccess)
             return vbm_set_hip_error(err, "hipMemcpyAsync(wflags)");
         (void)hipEventRecord(e->ev_stage[t], st);
-        e->last_ids.assign(stream_ids, stream_ids + nsb);
-        e->last_flags.assign(wflags, wflags + nsb);
+        e->last_ids[w].assign(stream_ids, stream_ids + nsb);
+        e->last_flags[w].assign(wflags, wflags + nsb);
     }
 
     vbm_batch b;
-    configure(e, b, block_mode, nsb, d_pcm);
+    configure(e, b, block_mode, nsb, d_pcm, w);
     e->last_nsb = nsb;
     e->last_mode = block_mode;
 
     // slices: multiples of 64 stream-blocks
     const int tiles = (nsb + 63) / 64;
     int nsplit = e->nsplit < tiles ? e->nsplit : tiles;
-    if (nsplit < 1) nsplit = 1;
+    if (nsplit < 1 || two) nsplit = 1;   // the two-stream form already overlaps consecutive calls
 
     int W = b.W;
     int rc = 0;
@@ -468,7 +520,12 @@ extern "C" int vbm_analysis_batch(vbm_encoder *e, int block_mode, int nsb, const
             STAGE(4, q, RUN(vbm_launch_noisemask(&v, q)));
             STAGE(5, q, RUN(vbm_launch_tonemask(&v, q)));
         }
-        STAGE(6, q, RUN(vbm_launch_mix(&v, q)));
+        STAGE(6, q, { RUN(vbm_launch_mix(&v, q)); RUN(vbm_launch_block_state(&v, q)); });
+        if (two) {   // hand over to the back stream
+            if ((err = hipEventRecord(e->ev_front[w], q)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
+            if ((err = hipStreamWaitEvent(sback, e->ev_front[w], 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
+            q = sback;
+        }
         STAGE(7, q, RUN(vbm_launch_floor_fit(&v, q)));
         // loop C: floor encode, couple/quantise, residue + packet assembly
         STAGE(8, q, RUN(vbm_launch_floor_encode(&v, q)));
@@ -489,6 +546,10 @@ extern "C" int vbm_analysis_batch(vbm_encoder *e, int block_mode, int nsb, const
             if ((err = hipEventRecord(e->ev_join[part], q)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
             if ((err = hipStreamWaitEvent(st, e->ev_join[part], 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
         }
+    }
+    if (two) {
+        if ((err = hipEventRecord(e->ev_back[w], sback)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
+        e->back_pending[w] = true;
     }
     if (prof) e->prof_calls++;
 #undef STAGE
@@ -525,6 +586,13 @@ extern "C" int vbm_analysis_round(vbm_encoder *e, const int *counts, const int *
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     hipError_t err;
+    const int w = e->next;
+    e->next ^= 1;
+    e->cur = w;
+    if (e->back_pending[w]) {
+        if ((err = hipStreamWaitEvent(st, e->ev_back[w], 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
+        e->back_pending[w] = false;
+    }
     // ids / flags in the padded lane layout, through the pinned staging (always uploaded: the layout changes
     // from round to round)
     {
@@ -537,12 +605,12 @@ extern "C" int vbm_analysis_round(vbm_encoder *e, const int *counts, const int *
             memcpy(e->h_ids[t] + pad[m], stream_ids + off[m], counts[m] * sizeof(int));
             memcpy(e->h_flags[t] + pad[m], wflags + off[m], counts[m]);
         }
-        if ((err = hipMemcpyAsync(e->d_stream_id, e->h_ids[t], lanes * sizeof(int), hipMemcpyHostToDevice, st)) != hipSuccess ||
-            (err = hipMemcpyAsync(e->d_wflags, e->h_flags[t], lanes, hipMemcpyHostToDevice, st)) != hipSuccess)
+        if ((err = hipMemcpyAsync(e->d_stream_id[w], e->h_ids[t], lanes * sizeof(int), hipMemcpyHostToDevice, st)) != hipSuccess ||
+            (err = hipMemcpyAsync(e->d_wflags[w], e->h_flags[t], lanes, hipMemcpyHostToDevice, st)) != hipSuccess)
             return vbm_set_hip_error(err, "hipMemcpyAsync(round ids)");
         (void)hipEventRecord(e->ev_stage[t], st);
-        e->last_ids.clear();
-        e->last_flags.clear();
+        e->last_ids[w].clear();
+        e->last_flags[w].clear();
     }
     if ((err = hipEventRecord(e->ev_fork, st)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
     e->last_nsb = 0;
@@ -571,7 +639,7 @@ extern "C" int vbm_analysis_round(vbm_encoder *e, const int *counts, const int *
         hipStream_t q = e->sub[m];
         if ((err = hipStreamWaitEvent(q, e->ev_fork, 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
         vbm_batch full;
-        configure(e, full, m, counts[m], d_pcm);
+        configure(e, full, m, counts[m], d_pcm, w);
         vbm_batch v = slice_of(full, pad[m], counts[m]);
         v.pcm = d_pcm + (size_t)off[m] * e->ch * s->blocksizes[1];
         const int W = v.W;
@@ -587,6 +655,7 @@ extern "C" int vbm_analysis_round(vbm_encoder *e, const int *counts, const int *
         RUN(vbm_launch_noisemask(&v, q));
         RUN(vbm_launch_tonemask(&v, q));
         RUN(vbm_launch_mix(&v, q));
+        RUN(vbm_launch_block_state(&v, q));
         RUN(vbm_launch_floor_fit(&v, q));
         RUN(vbm_launch_floor_encode(&v, q));
         RUN(vbm_launch_couple_quantize(&v, q));
@@ -652,7 +721,7 @@ extern "C" int vbm_encoder_fetch(vbm_encoder *e, const char *name, void *d_out, 
 {
     if (!e || !name || e->last_nsb <= 0) return VBM_EINVAL;
     vbm_batch b;
-    configure(e, b, e->last_mode, e->last_nsb, nullptr);
+    configure(e, b, e->last_mode, e->last_nsb, nullptr, e->cur);
     hipStream_t st = (hipStream_t)stream;
     const vbm_setup *s = e->hs;
     const vbm_psy &p = s->psy[b.block_mode];

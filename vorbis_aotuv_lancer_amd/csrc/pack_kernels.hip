@@ -4,7 +4,10 @@
 // mapping0_forward loop C (reference lib/mapping0.c:1204-1313) for the VBR blob, as launches:
 //   k_pack_head     packet type / mode / window bits :1211-1218; floor1_encode's bit emission
 //                   (lib/floor1.c:856-942); nonzero[] propagation over the coupling steps
-//                   (lib/psy.c:5133-5140); block-state update :1297-1305.  Serial, short.
+//                   (lib/psy.c:5133-5140).  Serial, short.
+//   k_block_state   the aoTuV block-state update of lib/mapping0.c:1297-1305.  It only depends on the block
+//                   type and is launched right after offset_and_mix: the psychoacoustics of the stream's
+//                   next block read it, the rest of this block's path does not.
 //   per residue submap (lib/mapping0.c:1273-1295):
 //   k_res_vq        res*_class (_01class lib/res0.c:406-468, _2class :473-526) and the res2
 //                   interleave (:781-787) of its partition slice, then
@@ -277,24 +280,28 @@ __global__ void k_pack_head(vbm_batch b)
     }
     b.packet_bits[sb] = bw_finish(w);
 
-    // ---- aoTuV block-state update (lib/mapping0.c:1297-1305) --------------------------------
-    {
-        const int block_mode = b.block_mode;
-        int impadnum = b.st.impadnum[sid];
-        int lWbm = b.st.lW_block_mode[sid];
-        int lW_no = b.st.lW_no[sid];
-        if (block_mode >= 2) impadnum = 0;
-        if ((!lWbm) && (block_mode == 1)) impadnum = 1;
-        else if (impadnum && impadnum < 8) impadnum++;
-        if (lWbm == block_mode) lW_no++;
-        else lW_no = 1;
-        b.st.impadnum[sid] = impadnum;
-        b.st.lW_no[sid] = lW_no;
-        b.st.lW_block_mode[sid] = block_mode;
-    }
 }
 
 // classification of partitions [i0, i1) of one stream-block (res*_class) + the res2 interleave
+__global__ void k_block_state(vbm_batch b)
+{
+    const int sb = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sb >= b.nsb) return;
+    const int sid = b.stream_id[sb];
+    const int block_mode = b.block_mode;
+    int impadnum = b.st.impadnum[sid];
+    int lWbm = b.st.lW_block_mode[sid];
+    int lW_no = b.st.lW_no[sid];
+    if (block_mode >= 2) impadnum = 0;
+    if ((!lWbm) && (block_mode == 1)) impadnum = 1;
+    else if (impadnum && impadnum < 8) impadnum++;
+    if (lWbm == block_mode) lW_no++;
+    else lW_no = 1;
+    b.st.impadnum[sid] = impadnum;
+    b.st.lW_no[sid] = lW_no;
+    b.st.lW_block_mode[sid] = block_mode;
+}
+
 __device__ __forceinline__ void res_classify(const vbm_batch &b, const res_view &v, const int sb, const size_t col0, const int i0, const int i1)
 {
     const vbm_residue *r = v.r;
@@ -506,6 +513,12 @@ __global__ void k_res_emit(vbm_batch b, int sm, int nchunks)
 }
 
 }  // namespace
+
+extern "C" int vbm_launch_block_state(const vbm_batch *b, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_block_state, dim3((unsigned)((b->nsb + 63) / 64)), dim3(64), 0, st, *b);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 
 extern "C" int vbm_launch_pack(const vbm_batch *b, hipStream_t st)
 {

@@ -60,9 +60,12 @@ class Encoder:
     def reset(self):
         check(lib.vbm_encoder_reset(self._h), "vbm_encoder_reset")
 
-    def analysis_batch(self, block_mode, stream_ids, wflags, pcm):
+    def analysis_batch(self, block_mode, stream_ids, wflags, pcm, back_stream=None, out=None):
         """pcm: CUDA float32 tensor [nsb, channels, blocksize]; returns (packets uint8 [nsb, max_bytes],
-        nbytes int32 [nsb]) on the device."""
+        nbytes int32 [nsb]) on the device.  back_stream (torch.cuda.Stream): run the second half of the path
+        (floor, couple/quantise, packets) there, so that it overlaps the first half of the next call
+        (vbm_analysis_batch2); the outputs are then ready on back_stream and must be passed in as `out`
+        (tensors the caller keeps alive)."""
         ids = np.ascontiguousarray(stream_ids, dtype=np.int32)
         fl = np.ascontiguousarray(wflags, dtype=np.uint8)
         nsb = len(ids)
@@ -70,11 +73,17 @@ class Encoder:
         if not (pcm.is_cuda and pcm.dtype == torch.float32 and pcm.is_contiguous()
                 and tuple(pcm.shape) == (nsb, self.setup.channels, N)):
             raise ValueError(f"pcm must be a contiguous CUDA float32 tensor of shape ({nsb}, {self.setup.channels}, {N})")
-        packets = torch.empty((nsb, self.max_packet_bytes), dtype=torch.uint8, device=pcm.device)
-        nbytes = torch.empty((nsb,), dtype=torch.int32, device=pcm.device)
+        if out is not None:
+            packets, nbytes = out
+        elif back_stream is not None:
+            raise ValueError("back_stream needs caller-owned output tensors (out=...)")
+        else:
+            packets = torch.empty((nsb, self.max_packet_bytes), dtype=torch.uint8, device=pcm.device)
+            nbytes = torch.empty((nsb,), dtype=torch.int32, device=pcm.device)
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        check(lib.vbm_analysis_batch(self._h, block_mode, nsb, ids.ctypes.data, fl.ctypes.data, pcm.data_ptr(),
-                                     packets.data_ptr(), nbytes.data_ptr(), st), "vbm_analysis_batch")
+        sb = st if back_stream is None else C.c_void_p(back_stream.cuda_stream)
+        check(lib.vbm_analysis_batch2(self._h, block_mode, nsb, ids.ctypes.data, fl.ctypes.data, pcm.data_ptr(),
+                                      packets.data_ptr(), nbytes.data_ptr(), st, sb), "vbm_analysis_batch2")
         self._last = (nsb, pcm.device)
         return packets, nbytes
 
