@@ -250,11 +250,34 @@ def main():
         if tj.get("channel_blocks_per_step") == ncb and tj.get("sub_batches") == sub:
             traffic = tj.get("hbm_bytes_per_launch", {})
 
+    # The MDCT kernel on its own (same launch shape as in the pipeline: one long block of every channel),
+    # timed with HIP events inside the library on this stream: the kernel's own HBM rate.  Inside the
+    # pipeline it shares the GPU with the previous step's back half (vbm_analysis_batch2), which is what
+    # stage_ms_per_launch["window_mdct"] shows.
+    mdct_alone_ms = None
+    if not args.from_pcm:
+        import ctypes as C
+        lk = v.MdctLookup(N_LONG, short_n=256)
+        x = blocks[0].reshape(ncb, N_LONG)
+        y = torch.empty((ncb, N_LONG // 2), device=dev)
+        ms = C.c_float()
+        st_ = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        v.check(v.lib.vbm_window_mdct_time(lk._h, x.data_ptr(), y.data_ptr(), None, ncb, 3, st_, C.byref(ms)))
+        v.check(v.lib.vbm_window_mdct_time(lk._h, x.data_ptr(), y.data_ptr(), None, ncb, 20, st_, C.byref(ms)))
+        mdct_alone_ms = ms.value / 20
+
     if rank == 0:
         r_dom = roof(dominant)
         r_dom["traffic"] = traffic.get(dominant)
         r_mdct = roof("window_mdct")
         r_mdct["traffic"] = traffic.get("window_mdct")
+        if mdct_alone_ms:
+            r_mdct["in_pipeline_ms"] = r_mdct["kernel_ms"]
+            r_mdct["in_pipeline_frac"] = r_mdct["frac"]
+            r_mdct["kernel_ms"] = mdct_alone_ms
+            r_mdct["achieved"] = r_mdct["algorithmic_bytes_per_launch"] / (mdct_alone_ms * 1e-3) / 1e9
+            r_mdct["frac"] = r_mdct["achieved"] / HBM_PEAK_GBPS
+            r_mdct["note"] = "kernel alone, 20 launches of the step's blocks; in_pipeline_* = beside the previous step's back half"
         mean_bytes = float(nb.float().mean().item())
         line = {
             "metric": "realtime-stream-equivalents/node (44.1kHz stereo q5) + MDCT HBM GB/s",
