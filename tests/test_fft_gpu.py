@@ -19,6 +19,30 @@ def signal(rng, shape):
     return x.astype(np.float32)
 
 
+@pytest.mark.parametrize("n,nblocks", [(1024, 1), (1024, 70), (512, 3), (512, 300)])
+def test_window_fft_log_512_1024(oracle, cuda, n, nblocks):
+    """block sizes of the 22/16/11/8 kHz modes: 1024 over 512 (variable window halves) and plain 512"""
+    import vorbis_aotuv_lancer_amd as v
+    from vorbis_aotuv_lancer_amd.tables import window_table
+    rng = np.random.default_rng(n * 3 + nblocks)
+    x = signal(rng, (nblocks, n))
+    lk = v.MdctLookup(n, short_n=512)
+    assert np.array_equal(bits(lk.fft_twiddles), bits(orc.fft_twiddles(oracle, n)))
+    wl, ws = window_table(1024), window_table(512)
+    if n == 1024:
+        flags = rng.integers(0, 4, nblocks).astype(np.uint8)
+        w = np.stack([oracle.apply_window(x[i], wl if flags[i] & 1 else ws, wl if flags[i] & 2 else ws)
+                      for i in range(nblocks)])
+        tf = torch.from_numpy(flags).to(cuda)
+    else:
+        w = oracle.apply_window(x, ws, ws)
+        tf = None
+    ref_log, ref_amp = orc.fft_logpower(oracle, w)
+    got_log, got_amp = v.window_fft_log(lk, torch.from_numpy(x).to(cuda), tf)
+    assert np.array_equal(bits(got_log.cpu().numpy()), bits(ref_log))
+    assert np.array_equal(bits(got_amp.cpu().numpy()), bits(ref_amp))
+
+
 @pytest.mark.parametrize("n,nblocks", [(2048, 1), (2048, 5), (2048, 300), (256, 1), (256, 9), (256, 700)])
 def test_window_fft_log_bit_exact(oracle, cuda, n, nblocks):
     import vorbis_aotuv_lancer_amd as v

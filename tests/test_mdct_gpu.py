@@ -16,7 +16,7 @@ def signal(rng, shape):
     return x
 
 
-@pytest.mark.parametrize("n", [2048, 256])
+@pytest.mark.parametrize("n", [2048, 1024, 512, 256])
 @pytest.mark.parametrize("nblocks", [1, 3, 8, 9, 67, 1000])
 def test_mdct_forward_bit_exact(oracle, cuda, n, nblocks):
     import vorbis_aotuv_lancer_amd as v
@@ -49,6 +49,26 @@ def test_window_mdct_long_all_neighbour_types(oracle, cuda, nblocks):
     got2 = v.window_mdct(lk, torch.from_numpy(x).to(cuda)).cpu().numpy()
     ref2 = oracle.mdct_forward(oracle.apply_window(x, wl, wl))
     assert np.array_equal(bits(got2), bits(ref2))
+
+
+@pytest.mark.parametrize("nblocks", [1, 5, 130])
+def test_window_mdct_long_1024_over_512(oracle, cuda, nblocks):
+    """the 512/1024 block pair of the 22 kHz and 16 kHz modes (lib/modes/setup_22.h, setup_16.h)"""
+    import vorbis_aotuv_lancer_amd as v
+    from vorbis_aotuv_lancer_amd.tables import window_table
+    rng = np.random.default_rng(50 + nblocks)
+    x = signal(rng, (nblocks, 1024))
+    flags = rng.integers(0, 4, nblocks).astype(np.uint8)
+    lk = v.MdctLookup(1024, short_n=512)
+    got = v.window_mdct(lk, torch.from_numpy(x).to(cuda), torch.from_numpy(flags).to(cuda)).cpu().numpy()
+    wl, ws = window_table(1024), window_table(512)
+    ref = np.stack([oracle.mdct_forward(oracle.apply_window(x[i], wl if flags[i] & 1 else ws, wl if flags[i] & 2 else ws))
+                    for i in range(nblocks)])
+    assert np.array_equal(bits(got), bits(ref))
+    xs = signal(rng, (nblocks, 512))
+    lks = v.MdctLookup(512, short_n=512)
+    gots = v.window_mdct(lks, torch.from_numpy(xs).to(cuda)).cpu().numpy()
+    assert np.array_equal(bits(gots), bits(oracle.mdct_forward(oracle.apply_window(xs, ws, ws))))
 
 
 @pytest.mark.parametrize("nblocks", [1, 7, 8, 200])

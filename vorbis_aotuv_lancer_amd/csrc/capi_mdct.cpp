@@ -125,8 +125,10 @@ extern "C" int vbm_mdct_plan_create(vbm_mdct_plan **out, int n, int short_n,
 {
     if (!out) return VBM_EINVAL;
     *out = nullptr;
-    if (n != 2048 && n != 256) return VBM_EIMPL;
-    if (n == 2048 && win_n && (!win_short || short_n <= 0 || short_n > n || (short_n & 7))) return VBM_EINVAL;
+    if (n != 2048 && n != 1024 && n != 512 && n != 256) return VBM_EIMPL;
+    // a plan with a second (short) window serves long blocks, whose halves take either shape
+    const bool is_long = win_n && win_short && short_n > 0 && short_n < n;
+    if (win_short && win_n && (short_n <= 0 || short_n > n || (short_n & 7))) return VBM_EINVAL;
     int ndev = vbm_device_count();
     if (ndev < 0) return ndev;
     if (ndev == 0) {
@@ -135,7 +137,7 @@ extern "C" int vbm_mdct_plan_create(vbm_mdct_plan **out, int n, int short_n,
     }
     vbm_mdct_plan *p = new vbm_mdct_plan();
     p->n = n;
-    p->short_n = (n == 2048) ? short_n : n;
+    p->short_n = is_long ? short_n : n;
     p->has_window = win_n != nullptr;
     p->d_trig = p->d_win_n = p->d_win_short = p->d_fftwa = nullptr;
     build_trig(p->trig, n);
@@ -149,7 +151,7 @@ extern "C" int vbm_mdct_plan_create(vbm_mdct_plan **out, int n, int short_n,
     if (win_n) {
         CK(hipMalloc((void **)&p->d_win_n, (n / 2) * sizeof(float)));
         CK(hipMemcpy(p->d_win_n, win_n, (n / 2) * sizeof(float), hipMemcpyHostToDevice));
-        if (n == 2048) {
+        if (is_long) {
             CK(hipMalloc((void **)&p->d_win_short, (short_n / 2) * sizeof(float)));
             CK(hipMemcpy(p->d_win_short, win_short, (short_n / 2) * sizeof(float), hipMemcpyHostToDevice));
         }
@@ -196,8 +198,8 @@ extern "C" int vbm_window_mdct_batch(const vbm_mdct_plan *p, const float *d_pcm,
     int rc = check_batch_args(p, d_pcm, d_out, nblocks);
     if (rc) return rc;
     if (!p->has_window) return VBM_EINVAL;
-    rc = vbm_launch_window_mdct(d_pcm, d_out, d_wflags, p->d_trig, p->d_win_n, p->d_win_short, p->n,
-                                p->short_n, 1, nblocks, 0, (hipStream_t)stream);
+    rc = vbm_launch_window_mdct(d_pcm, d_out, p->d_win_short ? d_wflags : nullptr, p->d_trig, p->d_win_n, p->d_win_short,
+                                p->n, p->short_n, 1, nblocks, 0, (hipStream_t)stream);
     return rc ? VBM_EHIP : VBM_OK;
 }
 
@@ -208,8 +210,8 @@ extern "C" int vbm_window_fft_log_batch(const vbm_mdct_plan *p, const float *d_p
     int rc = check_batch_args(p, d_pcm, d_logfft, nblocks);
     if (rc) return rc;
     if (!p->has_window || (nblocks > 0 && !d_local_ampmax)) return VBM_EINVAL;
-    rc = vbm_launch_window_fft_log(d_pcm, d_logfft, d_local_ampmax, d_wflags, p->d_fftwa, p->d_win_n,
-                                   p->d_win_short, p->n, p->short_n, nblocks, (hipStream_t)stream);
+    rc = vbm_launch_window_fft_log(d_pcm, d_logfft, d_local_ampmax, p->d_win_short ? d_wflags : nullptr, p->d_fftwa,
+                                   p->d_win_n, p->d_win_short, p->n, p->short_n, nblocks, (hipStream_t)stream);
     return rc ? VBM_EHIP : VBM_OK;
 }
 

@@ -172,6 +172,41 @@ __device__ __forceinline__ void fft_forward<256>(float *c, float *ch, const floa
     wave_lds_sync();
 }
 
+// n = 1024: ifac = {4,4,4,4,4}   ->  passes (4,256,1) (4,64,4) (4,16,16) (4,4,64) (4,1,256); result in ch
+// n = 512 : ifac = {2,4,4,4,4}   ->  passes (4,128,1) (4,32,4) (4,8,16) (4,2,64) (2,1,256);  result in ch
+template <>
+__device__ __forceinline__ void fft_forward<1024>(float *c, float *ch, const float *wa, int lane)
+{
+    radf4_pass<1, 256>(c, ch, wa + 1020, wa + 1021, wa + 1022, lane);    // iw = 1024-3 = 1021
+    wave_lds_sync();
+    radf4_pass<4, 64>(ch, c, wa + 1008, wa + 1012, wa + 1016, lane);     // iw = 1021-12 = 1009
+    wave_lds_sync();
+    radf4_pass<16, 16>(c, ch, wa + 960, wa + 976, wa + 992, lane);       // iw = 1009-48 = 961
+    wave_lds_sync();
+    radf4_pass<64, 4>(ch, c, wa + 768, wa + 832, wa + 896, lane);        // iw = 961-192 = 769
+    wave_lds_sync();
+    radf4_pass<256, 1>(c, ch, wa + 0, wa + 256, wa + 512, lane);         // iw = 769-768 = 1
+    wave_lds_sync();
+}
+
+template <>
+__device__ __forceinline__ void fft_forward<512>(float *c, float *ch, const float *wa, int lane)
+{
+    radf4_pass<1, 128>(c, ch, wa + 508, wa + 509, wa + 510, lane);       // iw = 512-3 = 509
+    wave_lds_sync();
+    radf4_pass<4, 32>(ch, c, wa + 496, wa + 500, wa + 504, lane);        // iw = 509-12 = 497
+    wave_lds_sync();
+    radf4_pass<16, 8>(c, ch, wa + 448, wa + 464, wa + 480, lane);        // iw = 497-48 = 449
+    wave_lds_sync();
+    radf4_pass<64, 2>(ch, c, wa + 256, wa + 320, wa + 384, lane);        // iw = 449-192 = 257
+    wave_lds_sync();
+    radf2_pass<256, 1>(c, ch, wa + 0, lane);                             // iw = 257-256 = 1
+    wave_lds_sync();
+}
+
+// after an odd number of passes the spectrum sits in the second buffer (drftf1 copies it back, :6163-6169)
+template <int N> struct fft_result_in_ch { static constexpr bool value = (N == 1024 || N == 512); };
+
 template <int N>
 __global__ __launch_bounds__(64 * WAVES_PER_WG)
 void k_window_fft_log(const float *__restrict__ pcm, float *__restrict__ logfft,
@@ -182,7 +217,7 @@ void k_window_fft_log(const float *__restrict__ pcm, float *__restrict__ logfft,
 {
     __shared__ __attribute__((aligned(16))) float s_wa[N];
     __shared__ __attribute__((aligned(16))) float s_win[N / 2];
-    __shared__ __attribute__((aligned(16))) float s_wshort[(N == 2048) ? 512 : 4];
+    __shared__ __attribute__((aligned(16))) float s_wshort[N / 4];   // rising half-window of a short block (<= N/2 long)
     __shared__ __attribute__((aligned(16))) float s_buf[WAVES_PER_WG][2][N];
 
     const int tid = threadIdx.x;
@@ -190,8 +225,8 @@ void k_window_fft_log(const float *__restrict__ pcm, float *__restrict__ logfft,
     const int wave = tid >> 6;
     for (int i = tid; i < N; i += blockDim.x) s_wa[i] = wa_g[i];
     for (int i = tid; i < N / 2; i += blockDim.x) s_win[i] = win_self[i];
-    if (N == 2048)
-        for (int i = tid; i < (short_n >> 1); i += blockDim.x) s_wshort[i] = win_short[i];
+    if (wflags)
+        for (int i = tid; i < (short_n >> 1) && i < N / 4; i += blockDim.x) s_wshort[i] = win_short[i];
     __syncthreads();
 
     float *c = s_buf[wave][0];
@@ -203,7 +238,7 @@ void k_window_fft_log(const float *__restrict__ pcm, float *__restrict__ logfft,
         // ---- load + window (lib/window.c:2137-2258) into LDS ----------------------------
         int ln = N, rn = N;
         const float *wl = s_win, *wr = s_win;
-        if (N == 2048 && wflags) {
+        if (wflags) {
             int f = wflags[blk];
             if (!(f & 1)) { ln = short_n; wl = s_wshort; }
             if (!(f & 2)) { rn = short_n; wr = s_wshort; }
@@ -234,19 +269,20 @@ void k_window_fft_log(const float *__restrict__ pcm, float *__restrict__ logfft,
         wave_lds_sync();
 
         fft_forward<N>(c, ch, s_wa, lane);
+        const float *spec = fft_result_in_ch<N>::value ? ch : c;
 
         // ---- log power spectrum + block maximum (lib/mapping0.c:848-888) -----------------
         float *o = logfft + blk * (N / 2);
         float mx;
         {
             // bin 0 by lane 0; its value seeds the running maximum (:862)
-            float v0 = (float)((double)(scale_dB + todB(c[0])) + .345);
+            float v0 = (float)((double)(scale_dB + todB(spec[0])) + .345);
             mx = v0;
             if (lane == 0) o[0] = v0;
         }
         for (int m = 1 + lane; m < N / 2; m += 64) {
             int j = 2 * m - 1;
-            float re = c[j], im = c[j + 1];
+            float re = spec[j], im = spec[j + 1];
             float temp = re * re + im * im;
             float v = (float)((double)(scale_dB + .5f * todB(temp)) + .345);
             o[m] = v;
@@ -271,15 +307,17 @@ extern "C" int vbm_launch_window_fft_log(const float *d_pcm, float *d_logfft, fl
                                          hipStream_t stream)
 {
     if (nblocks <= 0) return 0;
-    if (n != 2048 && n != 256) return -1;
+    if (n != 2048 && n != 1024 && n != 512 && n != 256) return -1;
     long wgs = (nblocks + WAVES_PER_WG - 1) / WAVES_PER_WG;
     if (wgs > 256 * 2) wgs = 256 * 2;
     dim3 grid((unsigned)wgs), block(64 * WAVES_PER_WG);
-    if (n == 2048)
-        hipLaunchKernelGGL(k_window_fft_log<2048>, grid, block, 0, stream, d_pcm, d_logfft, d_local_ampmax,
-                           d_wflags, d_wa, d_win_self, d_win_short, short_n, nblocks);
-    else
-        hipLaunchKernelGGL(k_window_fft_log<256>, grid, block, 0, stream, d_pcm, d_logfft, d_local_ampmax,
-                           d_wflags, d_wa, d_win_self, d_win_short, short_n, nblocks);
+#define LAUNCH_FFT(NN)                                                                                              \
+    hipLaunchKernelGGL(k_window_fft_log<NN>, grid, block, 0, stream, d_pcm, d_logfft, d_local_ampmax, d_wflags, d_wa, \
+                       d_win_self, d_win_short, short_n, nblocks)
+    if (n == 2048) LAUNCH_FFT(2048);
+    else if (n == 1024) LAUNCH_FFT(1024);
+    else if (n == 512) LAUNCH_FFT(512);
+    else LAUNCH_FFT(256);
+#undef LAUNCH_FFT
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

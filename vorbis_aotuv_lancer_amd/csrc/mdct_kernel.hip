@@ -123,7 +123,7 @@ template <int N>
 struct Geo {
     static constexpr int C = N / 4;          // complex values per block after the fold
     static constexpr int BPG = 512 / C;      // blocks per 512-complex group
-    static constexpr int LOG2C = (N == 2048) ? 9 : (N == 256 ? 6 : 5);
+    static constexpr int LOG2C = (N == 2048) ? 9 : (N == 1024) ? 8 : (N == 512) ? 7 : (N == 256) ? 6 : 5;
     static constexpr int R2 = 3 * N / 16;    // first pair of fold region 3
     static constexpr int R1 = N / 16;        // first pair of fold region 2
 };
@@ -180,7 +180,7 @@ void k_window_mdct(const float *__restrict__ pcm, float *__restrict__ out,
 
     __shared__ __attribute__((aligned(16))) float s_trig[NTRIG];
     __shared__ __attribute__((aligned(16))) float s_win[(N == 128) ? N : N / 2];
-    __shared__ __attribute__((aligned(16))) float s_wshort[(N == 2048) ? 1024 : 4];
+    __shared__ __attribute__((aligned(16))) float s_wshort[N / 2];   // rising half-window of the short size, long blocks
     __shared__ __attribute__((aligned(16))) float2 s_x[WAVES_PER_WG][SLOTS];
 
     const int tid = threadIdx.x;
@@ -191,7 +191,7 @@ void k_window_mdct(const float *__restrict__ pcm, float *__restrict__ out,
     if (apply_window) {
         const int wn = (apply_window == 2 && N == 128) ? N : N / 2;
         for (int i = tid; i < wn; i += blockDim.x) s_win[i] = win_self[i];
-        if (N == 2048)
+        if (wflags)
             for (int i = tid; i < (short_n >> 1); i += blockDim.x) s_wshort[i] = win_short[i];
     }
     __syncthreads();
@@ -220,7 +220,7 @@ void k_window_mdct(const float *__restrict__ pcm, float *__restrict__ out,
             } else if (apply_window) {
                 int ln = N, rn = N;
                 const float *wl = s_win, *wr = s_win;
-                if (N == 2048 && wflags) {
+                if (wflags) {
                     long blk = group * G::BPG + b;
                     int f = (blk < nblocks) ? wflags[blk] : 3;
                     if (!(f & 1)) { ln = short_n; wl = s_wshort; }
@@ -256,26 +256,32 @@ void k_window_mdct(const float *__restrict__ pcm, float *__restrict__ out,
         if (next < ngroups) issue_loads<N, GATHER>(v, pcm, next, nblocks, lane, gather);
         wave_lds_sync();  // exchange slots are reused below
 
-        // ---------------- round A: index bits 8,7,6 (long blocks only) ----------------
-        if (N == 2048) {
+        // ---------------- round A: index bits 8,7,6 of the blocks that have them ----------
+        // trigint of the stage pairing index bit b is 4 << (LOG2C - 1 - b): the first butterfly of a block
+        // steps the table by 4, every later stage doubles it (lib/mdct.c:1105-1135)
+        if (G::LOG2C >= 9) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) {  // stage 0: trigint 4
+            for (int k = 0; k < 4; k++) {  // bit 8
                 int t = 255 - (lane + 64 * k);
                 bfly(c[k], c[k + 4], *reinterpret_cast<const float2 *>(s_trig + 4 * t));
             }
+        }
+        if (G::LOG2C >= 8) {
+            constexpr int TI = 4 << (G::LOG2C >= 8 ? G::LOG2C - 8 : 0);
 #pragma unroll
             for (int kb = 0; kb < 8; kb += 4)
 #pragma unroll
-                for (int k = 0; k < 2; k++) {  // stage 1: trigint 8
+                for (int k = 0; k < 2; k++) {  // bit 7
                     int t = 127 - (lane + 64 * k);
-                    bfly(c[kb + k], c[kb + k + 2], *reinterpret_cast<const float2 *>(s_trig + 8 * t));
+                    bfly(c[kb + k], c[kb + k + 2], *reinterpret_cast<const float2 *>(s_trig + TI * t));
                 }
-            {
-                int t = 63 - lane;  // stage 2: trigint 16
-                float2 w = *reinterpret_cast<const float2 *>(s_trig + 16 * t);
+        }
+        if (G::LOG2C >= 7) {
+            constexpr int TI = 4 << (G::LOG2C >= 7 ? G::LOG2C - 7 : 0);
+            int t = 63 - lane;  // bit 6
+            float2 w = *reinterpret_cast<const float2 *>(s_trig + TI * t);
 #pragma unroll
-                for (int kb = 0; kb < 8; kb += 2) bfly(c[kb], c[kb + 1], w);
-            }
+            for (int kb = 0; kb < 8; kb += 2) bfly(c[kb], c[kb + 1], w);
         }
 #pragma unroll
         for (int k = 0; k < 8; k++) sx[slot_addr(lane + 64 * k)] = c[k];
@@ -414,20 +420,22 @@ extern "C" int vbm_launch_window_mdct(const float *d_pcm, float *d_out, const ui
                                       hipStream_t stream)
 {
     if (nblocks <= 0) return 0;
-    if (n != 2048 && n != 256) return -1;
+    if (n != 2048 && n != 1024 && n != 512 && n != 256) return -1;
     const vbm_ve_gather none = {};
-    const int bpg = (n == 2048) ? 1 : 8;
+    const int bpg = 2048 / n;
     long ngroups = (nblocks + bpg - 1) / bpg;
     long wgs = (ngroups + WAVES_PER_WG - 1) / WAVES_PER_WG;
     if (max_workgroups <= 0) max_workgroups = 256 * 4;
     if (wgs > max_workgroups) wgs = max_workgroups;
     dim3 grid((unsigned)wgs), block(64 * WAVES_PER_WG);
-    if (n == 2048)
-        hipLaunchKernelGGL(k_window_mdct<2048>, grid, block, 0, stream, d_pcm, d_out, d_wflags,
-                           d_trig, d_win_self, d_win_short, short_n, apply_window, nblocks, none);
-    else
-        hipLaunchKernelGGL(k_window_mdct<256>, grid, block, 0, stream, d_pcm, d_out, d_wflags,
-                           d_trig, d_win_self, d_win_short, short_n, apply_window, nblocks, none);
+#define LAUNCH_MDCT(NN)                                                                                        \
+    hipLaunchKernelGGL(k_window_mdct<NN>, grid, block, 0, stream, d_pcm, d_out, d_wflags, d_trig, d_win_self, \
+                       d_win_short, short_n, apply_window, nblocks, none)
+    if (n == 2048) LAUNCH_MDCT(2048);
+    else if (n == 1024) LAUNCH_MDCT(1024);
+    else if (n == 512) LAUNCH_MDCT(512);
+    else LAUNCH_MDCT(256);
+#undef LAUNCH_MDCT
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
