@@ -222,6 +222,26 @@ int vbm_frontend_capacity(const vbm_frontend *fe);
 int vbm_frontend_encode_round(vbm_frontend *fe, uint8_t *d_packets, int *d_packet_bytes,
                               vbm_packet_info *info, int *nblocks, void *stream);
 
+/* ---- stream wrapper, host only ------------------------------------------------
+ * vbm_header_packets = vorbis_analysis_headerout (reference lib/info.c:636-717): the identification,
+ * comment and setup header packets of a setup, concatenated in buf with their sizes in lens[3]
+ * (buf == NULL: sizes only).  vendor NULL = the string of the reference's scalar build
+ * (lib/info.c:43).  They are packets 0..2 of a stream; the audio packets of
+ * vbm_frontend_encode_round follow with packetno 3...
+ * vbm_ogg_stream_* = libogg's ogg_stream_packetin / ogg_stream_pageout / ogg_stream_flush (libogg is
+ * external to the reference; page format per the reference's doc/framing.html): packetin queues a
+ * packet with the granulepos / e_o_s of its vbm_packet_info; pageout returns 1 and a pointer to a
+ * complete page (valid until the next call) when one is due, 0 otherwise; flush != 0 forces out
+ * what is queued (the reference application flushes after the three headers,
+ * examples/encoder_example.c:150-157). */
+int vbm_header_packets(const vbm_setup_handle *setup, const char *vendor, const char *const *comments,
+                       int ncomments, uint8_t *buf, long cap, long *lens);
+typedef struct vbm_ogg_stream vbm_ogg_stream;
+int vbm_ogg_stream_create(vbm_ogg_stream **os, int serialno);
+void vbm_ogg_stream_destroy(vbm_ogg_stream *os);
+int vbm_ogg_stream_packetin(vbm_ogg_stream *os, const uint8_t *packet, long bytes, int e_o_s, long long granulepos);
+int vbm_ogg_stream_pageout(vbm_ogg_stream *os, int flush, const uint8_t **page, long *bytes);
+
 /* Per-stage timing of vbm_analysis_batch: HIP events are recorded between the pipeline's kernels,
  * on the stream each kernel is launched on, for the next `max_calls` calls; profile_end waits for
  * the device and returns the summed milliseconds per stage over all launches

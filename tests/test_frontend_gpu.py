@@ -157,3 +157,46 @@ def test_frontend_other_mode_classes_match_oracle(oracle, cuda, ch, rate, q):
     # the 11 kHz and 8 kHz setups have a single block size: only block types 0 and 1 exist
     need = (0, 1) if rate < 16000 else (0, 1, 2, 3)
     frontend_vs_oracle(oracle, cuda, ch, rate, q, NS=6, seconds=1.7 if rate >= 16000 else 4.0, need_modes=need)
+
+
+def test_complete_ogg_stream(oracle, cuda):
+    """PCM -> device front end -> packets -> header packets + Ogg pages (N3): the file's pages parse back to
+    the three headers plus exactly the packets the oracle produces, granule positions end at the sample
+    count, e_o_s sits on the last page."""
+    import vorbis_aotuv_lancer_amd as v
+    from tests.test_stream_wrapper import parse_pages, packets_of, unpack_headers
+    ch, rate, q = 2, 44100, 0.5
+    nsamp = 50 * 1024
+    sig = synth_signal(ch, rate, nsamp, seed=77)
+    setup = v.Setup(ch, rate, q)
+    enc = v.Encoder(setup, 1)
+    fe = v.FrontEnd(enc)
+    got = [[]]
+    dev = torch.from_numpy(sig).to(cuda)
+    for at in range(0, nsamp, 1024):
+        fe.write(dev[None, :, at:at + 1024].contiguous())
+        drain(fe, got)
+    fe.finish()
+    drain(fe, got)
+    blob = v.write_ogg(setup, [p for _, p in got[0]], [(m[5], bool(m[4])) for m, _ in got[0]], serialno=7,
+                       comments=["ENCODER=mi355x"])
+    pages = parse_pages(blob)
+    pk = packets_of(pages)
+    hdr = v.header_packets(setup, ["ENCODER=mi355x"])
+    assert pk[:3] == hdr and pk[3:] == [p for _, p in got[0]]
+    unpack_headers(*pk[:3])
+    assert pages[0]["flags"] & 2 and pages[-1]["flags"] & 4 and pages[-1]["granule"] == nsamp
+    # the audio packets start on a fresh page after the headers (examples/encoder_example.c:150-157)
+    header_pages = [pg for pg in pages if pg["granule"] == 0]
+    assert sum(1 for pg in header_pages for lv in pg["lacing"] if lv < 255) == 3
+    # and they are the oracle's
+    st = orc.Stream(orc.Setup(oracle, ch, rate, q))
+    oracle.lib.orc_stream_set_capture(st.v, 0)
+    want = []
+    for at in range(0, nsamp, 1024):
+        st.write(sig[:, at:at + 1024])
+        want.extend(b["packet"] for b in st.blocks())
+    st.finish()
+    want.extend(b["packet"] for b in st.blocks())
+    st.close()
+    assert pk[3:] == want

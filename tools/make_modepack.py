@@ -568,6 +568,16 @@ def build(ch, rate, quality):
     out["info/rate"] = np.array([rate], np.int64)
     out["info/quality"] = np.array([float(f32(quality))], np.float64)
     out["info/base_setting"] = np.array([base], np.float64)
+    # vi->bitrate_upper / _nominal / _lower as the identification header carries them (lib/info.c:518-520):
+    # VBR leaves hi->bitrate_max/_min at 0 (lib/vorbisenc.c:883-884); nominal = setting_to_approx_bitrate
+    # (lib/vorbisenc.c:659-672), a double stored into a long
+    rm = t.rate_mapping
+    if rm in ("NULL", "0", 0, None):
+        nominal = -1
+    else:
+        r = [float(x) for x in val(rm)]
+        nominal = int((r[is_] * (1. - ds) + r[is_ + 1] * ds) * ch)
+    out["info/bitrates"] = np.array([0, nominal, 0], np.int64)
     out["info/template"] = np.frombuffer(t.name.encode(), dtype=np.uint8)
     out["info/blocksizes"] = np.array(blocksizes, I32)
     out["info/counts"] = np.array([nmodes, nmodes, len(floors), nres, len(books.names), npsy], I32)

@@ -11,6 +11,7 @@ from .tables import window_table  # noqa: F401
 from .mdct import MdctLookup, mdct_forward, window_mdct, window_fft_log  # noqa: F401
 
 from .encoder import Setup, Encoder, FrontEnd, PacketInfo  # noqa: F401,E402
+from .stream import header_packets, OggStream, write_ogg  # noqa: F401,E402
 
-__all__ = ["Setup", "Encoder", "FrontEnd", "PacketInfo", "lib", "LIB_PATH", "VbmError", "check", "window_table",
+__all__ = ["Setup", "Encoder", "FrontEnd", "PacketInfo", "header_packets", "OggStream", "write_ogg", "lib", "LIB_PATH", "VbmError", "check", "window_table",
            "MdctLookup", "mdct_forward", "window_mdct", "window_fft_log"]

@@ -63,6 +63,11 @@ SIGNATURES = {
     "vbm_frontend_max_buffered": (C.c_int, [C.c_void_p]),
     "vbm_frontend_capacity": (C.c_int, [C.c_void_p]),
     "vbm_frontend_encode_round": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]),
+    "vbm_header_packets": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_void_p, C.c_long, C.POINTER(C.c_long)]),
+    "vbm_ogg_stream_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "vbm_ogg_stream_destroy": (None, [C.c_void_p]),
+    "vbm_ogg_stream_packetin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_longlong]),
+    "vbm_ogg_stream_pageout": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_long)]),
     "vbm_encoder_stage_count": (C.c_int, []),
     "vbm_encoder_stage_name": (C.c_char_p, [C.c_int]),
     "vbm_host_mdct_trig": (C.c_int, [C.c_int, C.c_void_p]),

@@ -7,6 +7,7 @@
 
 struct vbm_setup_handle {
     vbm_setup_host *H;
+    std::string mode_path;   // the header packets are packed from the mode pack itself (capi_stream.cpp)
 };
 
 extern "C" int vbm_setup_create(vbm_setup_handle **out, const char *common_vpk, const char *mode_vpk)
@@ -19,7 +20,7 @@ extern "C" int vbm_setup_create(vbm_setup_handle **out, const char *common_vpk, 
         g_vbm_err = err;
         return VBM_EFAULT;
     }
-    *out = new vbm_setup_handle{H};
+    *out = new vbm_setup_handle{H, mode_vpk};
     return VBM_OK;
 }
 
@@ -31,6 +32,7 @@ extern "C" void vbm_setup_destroy(vbm_setup_handle *h)
 }
 
 vbm_setup_host *vbm_setup_handle_host(vbm_setup_handle *h) { return h ? h->H : nullptr; }
+const char *vbm_setup_handle_mode_path(const vbm_setup_handle *h) { return h ? h->mode_path.c_str() : ""; }
 
 // name -> (pointer, element count, element kind 'f' float / 'i' int32 / 'd' double / 'b' int8 / 'u' uint32)
 extern "C" int vbm_setup_table(const vbm_setup_handle *h, const char *name, const void **data, long *count,
