@@ -124,7 +124,9 @@ __device__ __forceinline__ void prefix_chain(const vbm_batch &b, const vbm_psy *
     const int n = p->n;
     const float offset = (PASS == 1) ? 140.f : 0.f;
     const float *__restrict__ src = (PASS == 1) ? b.mdctT : b.workT;
-    float *__restrict__ dst = b.sumT + (size_t)CHAIN * n * 64;
+    // the five sums of a bin sit next to each other: sumT[(bin * 5 + chain)][64] (the solve reads all five of a
+    // window edge at once: one 1280-byte run instead of five rows 256 KB apart)
+    float *__restrict__ dst = b.sumT + (size_t)CHAIN * 64;
     float *__restrict__ logmdct = b.logmdctT;
     float acc = 0.f, x = 0.f;
     double hi_th = 0;
@@ -160,7 +162,7 @@ __device__ __forceinline__ void prefix_chain(const vbm_batch &b, const vbm_psy *
                     if (CHAIN == 3) acc += w * y;
                     if (CHAIN == 4) acc += w * x * y;
                 }
-                T(dst, i + u) = acc;
+                T(dst, (i + u) * 5) = acc;
                 x += 1.f;
             }
         }
@@ -206,14 +208,11 @@ struct hy_abd { float A, B, D; };
 __device__ __forceinline__ hy_abd hybrid_abd(const float *__restrict__ sum, const size_t tb, const int n, const int lo,
                                              const int hi, const bool mirror)
 {
-    const float *__restrict__ N = sum;
-    const float *__restrict__ X = sum + (size_t)n * 64;
-    const float *__restrict__ XX = sum + (size_t)2 * n * 64;
-    const float *__restrict__ Y = sum + (size_t)3 * n * 64;
-    const float *__restrict__ XY = sum + (size_t)4 * n * 64;
+    (void)n;
     const int lo_ = mirror ? -lo : lo;
-    const float nh = T(N, hi), nl = T(N, lo_), xh = T(X, hi), xl = T(X, lo_), xxh = T(XX, hi), xxl = T(XX, lo_);
-    const float yh = T(Y, hi), yl = T(Y, lo_), xyh = T(XY, hi), xyl = T(XY, lo_);
+    const float *__restrict__ H = sum + tb + (size_t)hi * 5 * 64, *__restrict__ L = sum + tb + (size_t)lo_ * 5 * 64;
+    const float nh = H[0], xh = H[64], xxh = H[128], yh = H[192], xyh = H[256];
+    const float nl = L[0], xl = L[64], xxl = L[128], yl = L[192], xyl = L[256];
     float tN, tX, tXX, tY, tXY;
     if (mirror) {
         tN = nh + nl; tX = xh - xl; tXX = xxh + xxl; tY = yh + yl; tXY = xyh - xyl;
