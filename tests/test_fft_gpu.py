@@ -19,17 +19,17 @@ def signal(rng, shape):
     return x.astype(np.float32)
 
 
-@pytest.mark.parametrize("n,nblocks", [(1024, 1), (1024, 70), (512, 3), (512, 300)])
-def test_window_fft_log_512_1024(oracle, cuda, n, nblocks):
-    """block sizes of the 22/16/11/8 kHz modes: 1024 over 512 (variable window halves) and plain 512"""
+@pytest.mark.parametrize("n,nblocks", [(1024, 1), (1024, 70), (512, 3), (512, 300), (4096, 1), (4096, 40)])
+def test_window_fft_log_512_1024_4096(oracle, cuda, n, nblocks):
+    """block sizes of the 22/16/11/8 kHz modes (1024 over 512, plain 512) and of q < 0 (4096 over 512)"""
     import vorbis_aotuv_lancer_amd as v
     from vorbis_aotuv_lancer_amd.tables import window_table
     rng = np.random.default_rng(n * 3 + nblocks)
     x = signal(rng, (nblocks, n))
     lk = v.MdctLookup(n, short_n=512)
     assert np.array_equal(bits(lk.fft_twiddles), bits(orc.fft_twiddles(oracle, n)))
-    wl, ws = window_table(1024), window_table(512)
-    if n == 1024:
+    wl, ws = window_table(max(n, 1024)), window_table(512)
+    if n >= 1024:
         flags = rng.integers(0, 4, nblocks).astype(np.uint8)
         w = np.stack([oracle.apply_window(x[i], wl if flags[i] & 1 else ws, wl if flags[i] & 2 else ws)
                       for i in range(nblocks)])

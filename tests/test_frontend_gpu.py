@@ -152,6 +152,7 @@ def test_frontend_output_does_not_depend_on_round_policy(oracle, cuda):
     (2, 16000, 0.5),     # ve_setup_16_stereo: 512/1024 blocks
     (1, 11025, 0.5),     # ve_setup_11_uncoupled: one block size (512), one mode
     (1, 8000, 0.5),      # ve_setup_8_uncoupled
+    (2, 44100, -0.1),    # q < 0: 512/4096 blocks
 ])
 def test_frontend_other_mode_classes_match_oracle(oracle, cuda, ch, rate, q):
     # the 11 kHz and 8 kHz setups have a single block size: only block types 0 and 1 exist

@@ -16,7 +16,7 @@ def signal(rng, shape):
     return x
 
 
-@pytest.mark.parametrize("n", [2048, 1024, 512, 256])
+@pytest.mark.parametrize("n", [4096, 2048, 1024, 512, 256])
 @pytest.mark.parametrize("nblocks", [1, 3, 8, 9, 67, 1000])
 def test_mdct_forward_bit_exact(oracle, cuda, n, nblocks):
     import vorbis_aotuv_lancer_amd as v
@@ -69,6 +69,22 @@ def test_window_mdct_long_1024_over_512(oracle, cuda, nblocks):
     lks = v.MdctLookup(512, short_n=512)
     gots = v.window_mdct(lks, torch.from_numpy(xs).to(cuda)).cpu().numpy()
     assert np.array_equal(bits(gots), bits(oracle.mdct_forward(oracle.apply_window(xs, ws, ws))))
+
+
+@pytest.mark.parametrize("nblocks", [1, 6, 90])
+def test_window_mdct_long_4096_over_512(oracle, cuda, nblocks):
+    """the 512/4096 block pair of q < 0 at 44.1/48 kHz (lib/modes/setup_44.h:40-45)"""
+    import vorbis_aotuv_lancer_amd as v
+    from vorbis_aotuv_lancer_amd.tables import window_table
+    rng = np.random.default_rng(70 + nblocks)
+    x = signal(rng, (nblocks, 4096))
+    flags = rng.integers(0, 4, nblocks).astype(np.uint8)
+    lk = v.MdctLookup(4096, short_n=512)
+    got = v.window_mdct(lk, torch.from_numpy(x).to(cuda), torch.from_numpy(flags).to(cuda)).cpu().numpy()
+    wl, ws = window_table(4096), window_table(512)
+    ref = np.stack([oracle.mdct_forward(oracle.apply_window(x[i], wl if flags[i] & 1 else ws, wl if flags[i] & 2 else ws))
+                    for i in range(nblocks)])
+    assert np.array_equal(bits(got), bits(ref))
 
 
 @pytest.mark.parametrize("nblocks", [1, 7, 8, 200])

@@ -125,7 +125,7 @@ extern "C" int vbm_mdct_plan_create(vbm_mdct_plan **out, int n, int short_n,
 {
     if (!out) return VBM_EINVAL;
     *out = nullptr;
-    if (n != 2048 && n != 1024 && n != 512 && n != 256) return VBM_EIMPL;
+    if (n != 4096 && n != 2048 && n != 1024 && n != 512 && n != 256) return VBM_EIMPL;
     // a plan with a second (short) window serves long blocks, whose halves take either shape
     const bool is_long = win_n && win_short && short_n > 0 && short_n < n;
     if (win_short && win_n && (short_n <= 0 || short_n > n || (short_n & 7))) return VBM_EINVAL;

@@ -204,11 +204,32 @@ __device__ __forceinline__ void fft_forward<512>(float *c, float *ch, const floa
     wave_lds_sync();
 }
 
+// n = 4096: ifac = {4,4,4,4,4,4} ->  passes (4,1024,1) (4,256,4) (4,64,16) (4,16,64) (4,4,256) (4,1,1024); result in c
+template <>
+__device__ __forceinline__ void fft_forward<4096>(float *c, float *ch, const float *wa, int lane)
+{
+    radf4_pass<1, 1024>(c, ch, wa + 4092, wa + 4093, wa + 4094, lane);   // iw = 4096-3 = 4093
+    wave_lds_sync();
+    radf4_pass<4, 256>(ch, c, wa + 4080, wa + 4084, wa + 4088, lane);    // iw = 4093-12 = 4081
+    wave_lds_sync();
+    radf4_pass<16, 64>(c, ch, wa + 4032, wa + 4048, wa + 4064, lane);    // iw = 4081-48 = 4033
+    wave_lds_sync();
+    radf4_pass<64, 16>(ch, c, wa + 3840, wa + 3904, wa + 3968, lane);    // iw = 4033-192 = 3841
+    wave_lds_sync();
+    radf4_pass<256, 4>(c, ch, wa + 3072, wa + 3328, wa + 3584, lane);    // iw = 3841-768 = 3073
+    wave_lds_sync();
+    radf4_pass<1024, 1>(ch, c, wa + 0, wa + 1024, wa + 2048, lane);      // iw = 3073-3072 = 1
+    wave_lds_sync();
+}
+
 // after an odd number of passes the spectrum sits in the second buffer (drftf1 copies it back, :6163-6169)
 template <int N> struct fft_result_in_ch { static constexpr bool value = (N == 1024 || N == 512); };
 
+// waves per workgroup: two LDS buffers of N floats per wave; 4096-sample blocks leave room for two waves
+template <int N> struct fft_waves { static constexpr int value = (N == 4096) ? 2 : WAVES_PER_WG; };
+
 template <int N>
-__global__ __launch_bounds__(64 * WAVES_PER_WG)
+__global__ __launch_bounds__(64 * fft_waves<N>::value)
 void k_window_fft_log(const float *__restrict__ pcm, float *__restrict__ logfft,
                       float *__restrict__ local_ampmax, const uint8_t *__restrict__ wflags,
                       const float *__restrict__ wa_g,      // FFTPACK twiddles, N floats (trigcache + N)
@@ -218,7 +239,8 @@ void k_window_fft_log(const float *__restrict__ pcm, float *__restrict__ logfft,
     __shared__ __attribute__((aligned(16))) float s_wa[N];
     __shared__ __attribute__((aligned(16))) float s_win[N / 2];
     __shared__ __attribute__((aligned(16))) float s_wshort[N / 4];   // rising half-window of a short block (<= N/2 long)
-    __shared__ __attribute__((aligned(16))) float s_buf[WAVES_PER_WG][2][N];
+    constexpr int NW = fft_waves<N>::value;
+    __shared__ __attribute__((aligned(16))) float s_buf[NW][2][N];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -234,7 +256,7 @@ void k_window_fft_log(const float *__restrict__ pcm, float *__restrict__ logfft,
     const float scale = 4.f / N;
     const float scale_dB = (float)((double)todB(scale) + .345);  // lib/mapping0.c:795
 
-    for (long blk = (long)blockIdx.x * WAVES_PER_WG + wave; blk < nblocks; blk += (long)gridDim.x * WAVES_PER_WG) {
+    for (long blk = (long)blockIdx.x * NW + wave; blk < nblocks; blk += (long)gridDim.x * NW) {
         // ---- load + window (lib/window.c:2137-2258) into LDS ----------------------------
         int ln = N, rn = N;
         const float *wl = s_win, *wr = s_win;
@@ -307,14 +329,16 @@ extern "C" int vbm_launch_window_fft_log(const float *d_pcm, float *d_logfft, fl
                                          hipStream_t stream)
 {
     if (nblocks <= 0) return 0;
-    if (n != 2048 && n != 1024 && n != 512 && n != 256) return -1;
-    long wgs = (nblocks + WAVES_PER_WG - 1) / WAVES_PER_WG;
+    if (n != 4096 && n != 2048 && n != 1024 && n != 512 && n != 256) return -1;
+    const int nw = (n == 4096) ? 2 : WAVES_PER_WG;
+    long wgs = (nblocks + nw - 1) / nw;
     if (wgs > 256 * 2) wgs = 256 * 2;
-    dim3 grid((unsigned)wgs), block(64 * WAVES_PER_WG);
+    dim3 grid((unsigned)wgs), block(64 * nw);
 #define LAUNCH_FFT(NN)                                                                                              \
     hipLaunchKernelGGL(k_window_fft_log<NN>, grid, block, 0, stream, d_pcm, d_logfft, d_local_ampmax, d_wflags, d_wa, \
                        d_win_self, d_win_short, short_n, nblocks)
-    if (n == 2048) LAUNCH_FFT(2048);
+    if (n == 4096) LAUNCH_FFT(4096);
+    else if (n == 2048) LAUNCH_FFT(2048);
     else if (n == 1024) LAUNCH_FFT(1024);
     else if (n == 512) LAUNCH_FFT(512);
     else LAUNCH_FFT(256);

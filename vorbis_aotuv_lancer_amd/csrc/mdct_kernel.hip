@@ -164,6 +164,128 @@ __device__ __forceinline__ void issue_loads(float4 (&v)[8], const float *__restr
     }
 }
 
+// Radix rounds A, B, C on one 512-complex group held as c[k] = element lane + 64k: the butterfly stages of
+// mdct_butterflies (lib/mdct.c:1105-1135) for index bits 8..4 — those the block size has — and the 32-point
+// butterflies; the result is left in sx in natural order (slot 8*lane + k at padded address 9*lane + k).
+// LOG2C = log2 of the complex length of the transform the group belongs to (9: a 2048 block = the group;
+// 10: one half of a 4096 block after its first stage; 8, 7, 6, 5: two, four, eight, sixteen blocks per group).
+template <int LOG2C>
+__device__ __forceinline__ void radix_rounds(float2 (&c)[8], float2 *sx, const float *s_trig, const int lane)
+{
+        // ---------------- round A: index bits 8,7,6 of the blocks that have them ----------
+        // trigint of the stage pairing index bit b is 4 << (LOG2C - 1 - b): the first butterfly of a block
+        // steps the table by 4, every later stage doubles it (lib/mdct.c:1105-1135)
+        if (LOG2C >= 9) {
+            constexpr int TI = 4 << (LOG2C >= 9 ? LOG2C - 9 : 0);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {  // bit 8
+                int t = 255 - (lane + 64 * k);
+                bfly(c[k], c[k + 4], *reinterpret_cast<const float2 *>(s_trig + TI * t));
+            }
+        }
+        if (LOG2C >= 8) {
+            constexpr int TI = 4 << (LOG2C >= 8 ? LOG2C - 8 : 0);
+#pragma unroll
+            for (int kb = 0; kb < 8; kb += 4)
+#pragma unroll
+                for (int k = 0; k < 2; k++) {  // bit 7
+                    int t = 127 - (lane + 64 * k);
+                    bfly(c[kb + k], c[kb + k + 2], *reinterpret_cast<const float2 *>(s_trig + TI * t));
+                }
+        }
+        if (LOG2C >= 7) {
+            constexpr int TI = 4 << (LOG2C >= 7 ? LOG2C - 7 : 0);
+            int t = 63 - lane;  // bit 6
+            float2 w = *reinterpret_cast<const float2 *>(s_trig + TI * t);
+#pragma unroll
+            for (int kb = 0; kb < 8; kb += 2) bfly(c[kb], c[kb + 1], w);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) sx[slot_addr(lane + 64 * k)] = c[k];
+        wave_lds_sync();
+
+        // ---------------- round B: index bits 5,4 ------------------------------------
+        {
+            const int base = (lane >> 3) * 64 + (lane & 7);
+#pragma unroll
+            for (int k = 0; k < 8; k++) c[k] = sx[slot_addr(base + 8 * k)];
+            constexpr int MUL0 = (LOG2C >= 6) ? (4 << (LOG2C >= 6 ? LOG2C - 6 : 0)) : 0;  // trigint of the 64-complex stage
+            constexpr int MUL1 = 4 << (LOG2C - 5);  // trigint of the 32-complex stage
+            if (LOG2C >= 6) {   // 128-point blocks (32 complex) have no 64-complex stage
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    int t = 31 - ((lane & 7) + 8 * k);
+                    bfly(c[k], c[k + 4], *reinterpret_cast<const float2 *>(s_trig + MUL0 * t));
+                }
+            }
+#pragma unroll
+            for (int kb = 0; kb < 8; kb += 4)
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    int t = 15 - ((lane & 7) + 8 * k);
+                    bfly(c[kb + k], c[kb + k + 2], *reinterpret_cast<const float2 *>(s_trig + MUL1 * t));
+                }
+            wave_lds_sync();
+#pragma unroll
+            for (int k = 0; k < 8; k++) sx[slot_addr(base + 8 * k)] = c[k];
+        }
+        wave_lds_sync();
+
+        // ---------------- round C: 32-point butterflies (lib/mdct.c:602-658) ----------
+        float x[16];
+        {
+            // slots 8*lane .. 8*lane+7 are contiguous at padded address 9*lane (8-B units);
+            // 9*lane*8 bytes is only 8-B aligned, so read as float2
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                float2 t = sx[9 * lane + k];
+                x[2 * k] = t.x;
+                x[2 * k + 1] = t.y;
+            }
+        }
+        {
+            float y[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) y[j] = __shfl_xor(x[j], 1);
+            if (lane & 1) {
+                // upper half of the 32-block: x[16+j] += x[j]
+#pragma unroll
+                for (int j = 0; j < 16; j++) x[j] = x[j] + y[j];
+            } else {
+                // lower half: differences (upper - lower, or as the source has it) rotated
+                float r0, r1;
+                r0 = x[0] - y[0];   r1 = x[1] - y[1];
+                x[0] = r1 * K_PI3_8 + r0 * K_PI1_8;
+                x[1] = r1 * K_PI1_8 - r0 * K_PI3_8;
+                r0 = x[2] - y[2];   r1 = x[3] - y[3];
+                x[2] = (r1 + r0) * K_PI2_8;
+                x[3] = (r1 - r0) * K_PI2_8;
+                r0 = x[4] - y[4];   r1 = x[5] - y[5];
+                x[4] = r1 * K_PI1_8 + r0 * K_PI3_8;
+                x[5] = r1 * K_PI3_8 - r0 * K_PI1_8;
+                r0 = y[6] - x[6];   r1 = x[7] - y[7];
+                x[6] = r1;  x[7] = r0;
+                r0 = y[8] - x[8];   r1 = y[9] - x[9];
+                x[8] = r0 * K_PI3_8 - r1 * K_PI1_8;
+                x[9] = r1 * K_PI3_8 + r0 * K_PI1_8;
+                r0 = y[10] - x[10]; r1 = y[11] - x[11];
+                x[10] = (r0 - r1) * K_PI2_8;
+                x[11] = (r0 + r1) * K_PI2_8;
+                r0 = y[12] - x[12]; r1 = y[13] - x[13];
+                x[12] = r0 * K_PI1_8 - r1 * K_PI3_8;
+                x[13] = r0 * K_PI3_8 + r1 * K_PI1_8;
+                r0 = y[14] - x[14]; r1 = y[15] - x[15];
+                x[14] = r0;  x[15] = r1;
+            }
+        }
+        bfly16(x);
+        wave_lds_sync();
+#pragma unroll
+        for (int k = 0; k < 8; k++) sx[9 * lane + k] = make_float2(x[2 * k], x[2 * k + 1]);
+        wave_lds_sync();
+
+}
+
 template <int N, bool GATHER = false>
 __global__ __launch_bounds__(64 * WAVES_PER_WG)
 void k_window_mdct(const float *__restrict__ pcm, float *__restrict__ out,
@@ -256,116 +378,7 @@ void k_window_mdct(const float *__restrict__ pcm, float *__restrict__ out,
         if (next < ngroups) issue_loads<N, GATHER>(v, pcm, next, nblocks, lane, gather);
         wave_lds_sync();  // exchange slots are reused below
 
-        // ---------------- round A: index bits 8,7,6 of the blocks that have them ----------
-        // trigint of the stage pairing index bit b is 4 << (LOG2C - 1 - b): the first butterfly of a block
-        // steps the table by 4, every later stage doubles it (lib/mdct.c:1105-1135)
-        if (G::LOG2C >= 9) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) {  // bit 8
-                int t = 255 - (lane + 64 * k);
-                bfly(c[k], c[k + 4], *reinterpret_cast<const float2 *>(s_trig + 4 * t));
-            }
-        }
-        if (G::LOG2C >= 8) {
-            constexpr int TI = 4 << (G::LOG2C >= 8 ? G::LOG2C - 8 : 0);
-#pragma unroll
-            for (int kb = 0; kb < 8; kb += 4)
-#pragma unroll
-                for (int k = 0; k < 2; k++) {  // bit 7
-                    int t = 127 - (lane + 64 * k);
-                    bfly(c[kb + k], c[kb + k + 2], *reinterpret_cast<const float2 *>(s_trig + TI * t));
-                }
-        }
-        if (G::LOG2C >= 7) {
-            constexpr int TI = 4 << (G::LOG2C >= 7 ? G::LOG2C - 7 : 0);
-            int t = 63 - lane;  // bit 6
-            float2 w = *reinterpret_cast<const float2 *>(s_trig + TI * t);
-#pragma unroll
-            for (int kb = 0; kb < 8; kb += 2) bfly(c[kb], c[kb + 1], w);
-        }
-#pragma unroll
-        for (int k = 0; k < 8; k++) sx[slot_addr(lane + 64 * k)] = c[k];
-        wave_lds_sync();
-
-        // ---------------- round B: index bits 5,4 ------------------------------------
-        {
-            const int base = (lane >> 3) * 64 + (lane & 7);
-#pragma unroll
-            for (int k = 0; k < 8; k++) c[k] = sx[slot_addr(base + 8 * k)];
-            constexpr int MUL0 = (G::LOG2C >= 6) ? (4 << (G::LOG2C >= 6 ? G::LOG2C - 6 : 0)) : 0;  // trigint of the 64-complex stage
-            constexpr int MUL1 = 4 << (G::LOG2C - 5);  // trigint of the 32-complex stage
-            if (G::LOG2C >= 6) {   // 128-point blocks (32 complex) have no 64-complex stage
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    int t = 31 - ((lane & 7) + 8 * k);
-                    bfly(c[k], c[k + 4], *reinterpret_cast<const float2 *>(s_trig + MUL0 * t));
-                }
-            }
-#pragma unroll
-            for (int kb = 0; kb < 8; kb += 4)
-#pragma unroll
-                for (int k = 0; k < 2; k++) {
-                    int t = 15 - ((lane & 7) + 8 * k);
-                    bfly(c[kb + k], c[kb + k + 2], *reinterpret_cast<const float2 *>(s_trig + MUL1 * t));
-                }
-            wave_lds_sync();
-#pragma unroll
-            for (int k = 0; k < 8; k++) sx[slot_addr(base + 8 * k)] = c[k];
-        }
-        wave_lds_sync();
-
-        // ---------------- round C: 32-point butterflies (lib/mdct.c:602-658) ----------
-        float x[16];
-        {
-            // slots 8*lane .. 8*lane+7 are contiguous at padded address 9*lane (8-B units);
-            // 9*lane*8 bytes is only 8-B aligned, so read as float2
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                float2 t = sx[9 * lane + k];
-                x[2 * k] = t.x;
-                x[2 * k + 1] = t.y;
-            }
-        }
-        {
-            float y[16];
-#pragma unroll
-            for (int j = 0; j < 16; j++) y[j] = __shfl_xor(x[j], 1);
-            if (lane & 1) {
-                // upper half of the 32-block: x[16+j] += x[j]
-#pragma unroll
-                for (int j = 0; j < 16; j++) x[j] = x[j] + y[j];
-            } else {
-                // lower half: differences (upper - lower, or as the source has it) rotated
-                float r0, r1;
-                r0 = x[0] - y[0];   r1 = x[1] - y[1];
-                x[0] = r1 * K_PI3_8 + r0 * K_PI1_8;
-                x[1] = r1 * K_PI1_8 - r0 * K_PI3_8;
-                r0 = x[2] - y[2];   r1 = x[3] - y[3];
-                x[2] = (r1 + r0) * K_PI2_8;
-                x[3] = (r1 - r0) * K_PI2_8;
-                r0 = x[4] - y[4];   r1 = x[5] - y[5];
-                x[4] = r1 * K_PI1_8 + r0 * K_PI3_8;
-                x[5] = r1 * K_PI3_8 - r0 * K_PI1_8;
-                r0 = y[6] - x[6];   r1 = x[7] - y[7];
-                x[6] = r1;  x[7] = r0;
-                r0 = y[8] - x[8];   r1 = y[9] - x[9];
-                x[8] = r0 * K_PI3_8 - r1 * K_PI1_8;
-                x[9] = r1 * K_PI3_8 + r0 * K_PI1_8;
-                r0 = y[10] - x[10]; r1 = y[11] - x[11];
-                x[10] = (r0 - r1) * K_PI2_8;
-                x[11] = (r0 + r1) * K_PI2_8;
-                r0 = y[12] - x[12]; r1 = y[13] - x[13];
-                x[12] = r0 * K_PI1_8 - r1 * K_PI3_8;
-                x[13] = r0 * K_PI3_8 + r1 * K_PI1_8;
-                r0 = y[14] - x[14]; r1 = y[15] - x[15];
-                x[14] = r0;  x[15] = r1;
-            }
-        }
-        bfly16(x);
-        wave_lds_sync();
-#pragma unroll
-        for (int k = 0; k < 8; k++) sx[9 * lane + k] = make_float2(x[2 * k], x[2 * k + 1]);
-        wave_lds_sync();
+        radix_rounds<G::LOG2C>(c, sx, s_trig, lane);
 
         // ---------------- bit-reverse gather + post-twiddle + store -------------------
         {
@@ -411,6 +424,120 @@ void k_window_mdct(const float *__restrict__ pcm, float *__restrict__ out,
     }
 }
 
+// 4096-sample blocks (the long blocks of q < 0 at 44.1/48 kHz): 1024 complex values = two 512-complex
+// groups.  One wavefront per block: both halves are loaded, windowed and folded (the odd samples cross
+// between the halves through a 1024-slot LDS exchange), the first butterfly stage pairs element m with
+// m + 512 — both live in the same lane — and each half then runs the group rounds with the trig strides of
+// a 1024-complex transform; the bit-reverse gather reads across both halves.
+__global__ __launch_bounds__(64 * WAVES_PER_WG)
+void k_window_mdct_4096(const float *__restrict__ pcm, float *__restrict__ out, const uint8_t *__restrict__ wflags,
+                        const float *__restrict__ trig_g, const float *__restrict__ win_self,
+                        const float *__restrict__ win_short, int short_n, int apply_window, long nblocks)
+{
+    constexpr int N = 4096, C = 1024, R1 = N / 16, R2 = 3 * N / 16, NTRIG = N + N / 4;
+    __shared__ __attribute__((aligned(16))) float s_trig[NTRIG];
+    __shared__ __attribute__((aligned(16))) float s_win[N / 2];
+    __shared__ __attribute__((aligned(16))) float s_wshort[N / 8];
+    __shared__ __attribute__((aligned(16))) float2 s_x[WAVES_PER_WG][2][SLOTS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < NTRIG; i += blockDim.x) s_trig[i] = trig_g[i];
+    if (apply_window) {
+        for (int i = tid; i < N / 2; i += blockDim.x) s_win[i] = win_self[i];
+        if (wflags)
+            for (int i = tid; i < (short_n >> 1) && i < N / 8; i += blockDim.x) s_wshort[i] = win_short[i];
+    }
+    __syncthreads();
+
+    float2 *sx0 = s_x[wave][0], *sx1 = s_x[wave][1];
+#define SLOT(m) (((m) < 512 ? sx0 : sx1)[slot_addr((m) & 511)])
+    const float scale = 4.f / N;
+    for (long blk = (long)blockIdx.x * WAVES_PER_WG + wave; blk < nblocks; blk += (long)gridDim.x * WAVES_PER_WG) {
+        int ln = N, rn = N;
+        const float *wl = s_win, *wr = s_win;
+        if (apply_window && wflags) {
+            const int f = wflags[blk];
+            if (!(f & 1)) { ln = short_n; wl = s_wshort; }
+            if (!(f & 2)) { rn = short_n; wr = s_wshort; }
+        }
+        // ---------------- load, window, odd-sample exchange ---------------------------------
+        float2 ev[16];
+#pragma unroll
+        for (int kk = 0; kk < 16; kk++) {
+            const int p = lane + 64 * kk;   // pair index 0..1023 (kk < 8: first half)
+            const int q0 = (p < R2) ? (R2 - 1 - p) : (7 * N / 16 - 1 - p);
+            float4 d = *reinterpret_cast<const float4 *>(pcm + blk * N + 4 * q0);
+            if (apply_window) d = window4(d, 4 * q0, N, ln, rn, wl, wr);
+            ev[kk] = make_float2(d.x, d.z);
+            const int pp = (q0 >= R2) ? (q0 - R2) : (q0 + R1);
+            SLOT(pp) = make_float2(d.y, d.w);
+        }
+        wave_lds_sync();
+        // ---------------- fold + pre-twiddle (lib/mdct.c:1819-1851) -------------------------
+        float2 c0[8], c1[8];
+#pragma unroll
+        for (int kk = 0; kk < 16; kk++) {
+            const int p = lane + 64 * kk;
+            const float2 od = SLOT(p);
+            float a0 = ev[kk].y, a1 = ev[kk].x;
+            if (p >= R2) { a0 = -a0; a1 = -a1; }
+            float r0, r1;
+            if (p < R1) { r0 = a0 + od.x; r1 = a1 + od.y; }
+            else        { r0 = a0 - od.x; r1 = a1 - od.y; }
+            const float2 T = *reinterpret_cast<const float2 *>(s_trig + (N / 2 - 2 * (p + 1)));
+            float2 cv;
+            cv.x = r1 * T.y + r0 * T.x;
+            cv.y = r1 * T.x - r0 * T.y;
+            if (kk < 8) c0[kk] = cv;
+            else c1[kk - 8] = cv;
+        }
+        wave_lds_sync();
+        // ---------------- first stage: index bit 9, trigint 4 --------------------------------
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int t = 511 - (lane + 64 * k);
+            bfly(c0[k], c1[k], *reinterpret_cast<const float2 *>(s_trig + 4 * t));
+        }
+        radix_rounds<10>(c0, sx0, s_trig, lane);
+        radix_rounds<10>(c1, sx1, s_trig, lane);
+        // ---------------- bit-reverse gather + post-twiddle + store --------------------------
+#pragma unroll
+        for (int pass = 0; pass < 2; pass++) {
+            const int u0 = 4 * lane + 256 * pass;
+            float oA0[4], oA1[4], oB0[4], oB1[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int u = u0 + r;
+                const int rv = (int)(__brev((unsigned)u) >> (32 - 9));
+                const int s1 = 2 * rv, s0 = (C - 1) - 2 * rv;
+                const float2 X0 = SLOT(s0), X1 = SLOT(s1);
+                const float2 T = *reinterpret_cast<const float2 *>(s_trig + N + 2 * u);
+                const float r0 = X0.y - X1.y;
+                const float r1 = X0.x + X1.x;
+                const float r2 = r1 * T.x + r0 * T.y;
+                const float r3 = r1 * T.y - r0 * T.x;
+                const float h0 = (X0.y + X1.y) * .5f;
+                const float h1 = (X0.x - X1.x) * .5f;
+                const float2 wA = make_float2(h0 + r2, h1 + r3);
+                const float2 wB = make_float2(h0 - r2, r3 - h1);
+                const float2 TA = *reinterpret_cast<const float2 *>(s_trig + N / 2 + 2 * u);
+                const float2 TB = *reinterpret_cast<const float2 *>(s_trig + N / 2 + 2 * (C - 1 - u));
+                oA0[r] = (wA.x * TA.x + wA.y * TA.y) * scale;
+                oA1[r] = (wA.x * TA.y - wA.y * TA.x) * scale;
+                oB0[r] = (wB.x * TB.x + wB.y * TB.y) * scale;
+                oB1[r] = (wB.x * TB.y - wB.y * TB.x) * scale;
+            }
+            float *o = out + blk * (N / 2);
+            *reinterpret_cast<float4 *>(o + u0) = make_float4(oA0[0], oA0[1], oA0[2], oA0[3]);
+            *reinterpret_cast<float4 *>(o + C + u0) = make_float4(oB1[0], oB1[1], oB1[2], oB1[3]);
+            *reinterpret_cast<float4 *>(o + C - 4 - u0) = make_float4(oB0[3], oB0[2], oB0[1], oB0[0]);
+            *reinterpret_cast<float4 *>(o + 2 * C - 4 - u0) = make_float4(oA1[3], oA1[2], oA1[1], oA1[0]);
+        }
+        wave_lds_sync();
+    }
+#undef SLOT
+}
+
 }  // namespace
 
 extern "C" int vbm_launch_window_mdct(const float *d_pcm, float *d_out, const uint8_t *d_wflags,
@@ -420,6 +547,14 @@ extern "C" int vbm_launch_window_mdct(const float *d_pcm, float *d_out, const ui
                                       hipStream_t stream)
 {
     if (nblocks <= 0) return 0;
+    if (n == 4096) {
+        long wgs4 = (nblocks + WAVES_PER_WG - 1) / WAVES_PER_WG;
+        if (max_workgroups <= 0) max_workgroups = 256 * 4;
+        if (wgs4 > max_workgroups) wgs4 = max_workgroups;
+        hipLaunchKernelGGL(k_window_mdct_4096, dim3((unsigned)wgs4), dim3(64 * WAVES_PER_WG), 0, stream, d_pcm, d_out,
+                           d_wflags, d_trig, d_win_self, d_win_short, short_n, apply_window, nblocks);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     if (n != 2048 && n != 1024 && n != 512 && n != 256) return -1;
     const vbm_ve_gather none = {};
     const int bpg = 2048 / n;

@@ -500,8 +500,9 @@ vbm_setup_host *vbm_setup_host_load(const char *common_path, const char *mode_pa
         if (s.channels > VBM_MAXCH || s.floors > 4 || s.residues > 4 || s.psys > 4 || s.modes > 2)
             throw std::string("setup exceeds static limits");
         for (int b = 0; b < 2; b++)
-            if (s.blocksizes[b] != 256 && s.blocksizes[b] != 512 && s.blocksizes[b] != 1024 && s.blocksizes[b] != 2048)
-                throw std::string("block sizes 256/512/1024/2048 are implemented (4096: not yet)");
+            if (s.blocksizes[b] != 256 && s.blocksizes[b] != 512 && s.blocksizes[b] != 1024 && s.blocksizes[b] != 2048 &&
+                s.blocksizes[b] != 4096)
+                throw std::string("block sizes 256/512/1024/2048/4096 are implemented");
 
         for (int i = 0; i < s.maps; i++) {
             vbm_map &m = s.map[i];
