@@ -196,7 +196,6 @@ __global__ void k_pack_head(vbm_batch b)
     const vbm_map *info = &s->map[b.W];
     const int ch = b.ch;
     const size_t col0 = (size_t)sb * ch;
-    const int sid = b.stream_id[sb];
     int i, j, k;
 
     // nonzero[] after coupling (lib/psy.c:5133-5140); couple/quantise left the flags untouched

@@ -518,7 +518,6 @@ __global__ void k_tm_stamp(vbm_batch b, int nchunks)
     if (lane >= b.ncb) return;
     const size_t tb = TB(b, lane);
     const vbm_psy *p = psy_of(b);
-    const int n = p->n;
     const int sb = lane / b.ch;
     int *seed = (int *)b.seedT;
     const float *f = b.logfftT;
