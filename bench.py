@@ -321,7 +321,7 @@ def main():
             "stage_ms_per_step": per_step_ms,
             "sub_batches": sub,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # host baseline: rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if dist is not None:
