@@ -201,3 +201,23 @@ def test_complete_ogg_stream(oracle, cuda):
     want.extend(b["packet"] for b in st.blocks())
     st.close()
     assert pk[3:] == want
+
+
+def test_frontend_reproduces_reference_120s_len_crc(oracle, cuda):
+    """Two minutes of the probe signal from raw PCM: 5866 packets whose (length, crc32) the survey recorded
+    from the reference's scalar build (tests/golden/ref_scalar_2ch_44100_q05_120s.lencrc.npy)."""
+    import zlib
+    import vorbis_aotuv_lancer_amd as v
+    ref = np.load(os.path.join(G, "ref_scalar_2ch_44100_q05_120s.lencrc.npy"))
+    pcm = probe_pcm(oracle, 2, 44100, 120)
+    enc = v.Encoder(v.Setup(2, 44100, 0.5), 1)
+    fe = v.FrontEnd(enc)
+    got = [[]]
+    dev_pcm = torch.from_numpy(pcm).to(cuda)
+    for at in range(0, pcm.shape[1], 1024):
+        fe.write(dev_pcm[None, :, at:at + 1024].contiguous())
+        drain(fe, got)
+    pk = [p for _, p in got[0]]
+    assert len(pk) == ref.shape[0] == 5866
+    mine = np.array([(len(p), zlib.crc32(p)) for p in pk], dtype=np.uint32)
+    assert np.array_equal(mine, ref)
