@@ -496,10 +496,10 @@ __global__ void k_couple_quantize(vbm_batch b, int nchunks)
 
 // ---------------------------------------------------------------------------------------------
 // Fast path for 32-bin partitions (long blocks): one LANE per (column, bin) instead of one lane per
-// stream-block with per-partition arrays in private memory.  A workgroup of 1024 threads owns 32
+// stream-block with per-partition arrays in private memory.  A workgroup of FP x FPC threads owns FPC
 // columns x one partition: rows are loaded / stored with the column index fastest (coalesced 128-B
 // row segments of the tiled arrays) and transposed through LDS so that the 32 lanes of a half-wave
-// hold the 32 bins of one column's partition in registers.
+// hold the 32 bins of one column's partition in registers.  (FPC columns per workgroup.)
 //   MODE 0  no coupling: a column is a channel-block (any channel count, e.g. mono, 5.1 q8)
 //   MODE 1  stereo, one coupling step: a column is a stream-block, both channels in the lane
 // Per-bin work is elementwise.  The order-bound pieces of the source run as 32-step loops over the
@@ -507,7 +507,10 @@ __global__ void k_couple_quantize(vbm_batch b, int nchunks)
 // residue_def (:5018-5027).  noise_normalize's tail (sort + unit-norm promotion, :4800-4852) only
 // exists when normal_start falls inside the partition; then lane 0 of the half-wave runs the serial
 // routine above on LDS copies — the same code as the general kernel, so exact by construction.
-#define FP 32
+#define FP 32      /* bins of a partition */
+#ifndef FPC
+#define FPC 8      /* columns per workgroup: FP * FPC = 256 threads (measured 8 > 16 > 32 columns, pipelined) */
+#endif
 struct fast_consts {
     int limit, sliding_lowpass, lowpassr, tonefix_end, n;
     float prepoint, postpoint, prepoint_x, postpoint_x, prae;
@@ -515,11 +518,11 @@ struct fast_consts {
 };
 
 struct fast_lds {
-    float in_md[2][FP][FP + 1], in_ep[2][FP][FP + 1];
-    int in_iw[2][FP][FP + 1];
+    float in_md[2][FP][FPC + 1], in_ep[2][FP][FPC + 1];
+    int in_iw[2][FP][FPC + 1];
     // serial fallback of noise_normalize: per half-wave arrays
-    float r[FP][FP], q[FP][FP], f[FP][FP], res[FP][FP];
-    int flag[FP][FP], out[FP][FP];
+    float r[FPC][FP], q[FPC][FP], f[FPC][FP], res[FPC][FP];
+    int flag[FPC][FP], out[FPC][FP];
 };
 
 // per-channel part of a partition for this lane's bin (lib/psy.c:4952-4991)
@@ -589,7 +592,7 @@ __device__ __forceinline__ void fast_channel(const fast_consts &c, fast_lds &L, 
 }
 
 template <int MODE>
-__global__ __launch_bounds__(FP * FP) void k_couple_fast(vbm_batch b)
+__global__ __launch_bounds__(FP * FPC) void k_couple_fast(vbm_batch b)
 {
     __shared__ fast_lds L;
     const vbm_setup *s = b.setup;
@@ -622,8 +625,8 @@ __global__ __launch_bounds__(FP * FP) void k_couple_fast(vbm_batch b)
     const int tid = threadIdx.x;
 
     // ---- rows i..i+31 of the 32 columns of this workgroup: coalesced loads, LDS transpose -------
-    const int lr = tid >> 5, lc = tid & 31;
-    const int colL = blockIdx.x * FP + lc;
+    const int lr = tid / FPC, lc = tid % FPC;
+    const int colL = blockIdx.x * FPC + lc;
     const bool past = (i >= c.lowpassr);   // partitions past the lowpass only zero the residue (lib/psy.c:5126-5131)
     if (!past && colL < ncols && i + lr < c.n) {
 #pragma unroll
@@ -639,7 +642,7 @@ __global__ __launch_bounds__(FP * FP) void k_couple_fast(vbm_batch b)
 
     // ---- compute: lane = (column g, bin j) ---------------------------------------------------
     const int g = tid >> 5, j = tid & 31;
-    const int col = blockIdx.x * FP + g;
+    const int col = blockIdx.x * FPC + g;
     const int lane = tid & 63, base = lane & 32;
     const int jn = FP > c.n - i ? c.n - i : FP;
     int out[2] = {0, 0};
@@ -779,14 +782,14 @@ extern "C" int vbm_launch_couple_quantize(const vbm_batch *b, hipStream_t st)
     const unsigned tiles = (unsigned)((b->nsb + 63) / 64);
     // fast path: 32-bin partitions with no coupling, or stereo with one coupling step
     if (b->couple_fast == 1) {
-        hipLaunchKernelGGL(k_couple_fast<0>, dim3((unsigned)((b->ncb + FP - 1) / FP), (unsigned)(b->n / FP)), dim3(FP * FP), 0,
+        hipLaunchKernelGGL(k_couple_fast<0>, dim3((unsigned)((b->ncb + FPC - 1) / FPC), (unsigned)(b->n / FP)), dim3(FP * FPC), 0,
                            st, *b);
         return hipGetLastError() == hipSuccess ? 0 : -2;
     }
     if (b->couple_fast == 2) {
         if (b->couple_m6parts > 0)
             hipLaunchKernelGGL(k_couple_m6stats, dim3(tiles, (unsigned)b->couple_m6parts), dim3(64), 0, st, *b);
-        hipLaunchKernelGGL(k_couple_fast<1>, dim3((unsigned)((b->nsb + FP - 1) / FP), (unsigned)(b->n / FP)), dim3(FP * FP), 0,
+        hipLaunchKernelGGL(k_couple_fast<1>, dim3((unsigned)((b->nsb + FPC - 1) / FPC), (unsigned)(b->n / FP)), dim3(FP * FPC), 0,
                            st, *b);
         return hipGetLastError() == hipSuccess ? 0 : -2;
     }
