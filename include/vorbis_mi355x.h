@@ -214,6 +214,13 @@ void vbm_frontend_destroy(vbm_frontend *fe);
 int vbm_frontend_reset(vbm_frontend *fe);
 int vbm_frontend_write(vbm_frontend *fe, const float *d_pcm, int vals, void *stream);
 int vbm_frontend_finish(vbm_frontend *fe, const int *stream_ids, int n, void *stream);
+/* Streams that do not move in lock step: write `vals` samples to the listed streams only (d_pcm:
+ * [n][channels][vals], one entry per listed stream, a stream at most once per call), and start a
+ * new stream in listed slots (state of vorbis_analysis_init for the front end and the encoder;
+ * typically after the slot's previous stream has delivered its e_o_s packet). */
+int vbm_frontend_write_streams(vbm_frontend *fe, const int *stream_ids, int n, const float *d_pcm, int vals,
+                               void *stream);
+int vbm_frontend_restart_streams(vbm_frontend *fe, const int *stream_ids, int n, void *stream);
 /* Buffer occupancy, for callers that do not drain completely after every write (a stream inside a
  * run of short blocks yields up to 8 blocks per 1024 samples, each in its own round): the most
  * samples any stream holds now, and the occupancy a write may not exceed (VBM_EINVAL beyond it). */

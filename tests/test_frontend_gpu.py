@@ -221,3 +221,61 @@ def test_frontend_reproduces_reference_120s_len_crc(oracle, cuda):
     assert len(pk) == ref.shape[0] == 5866
     mine = np.array([(len(p), zlib.crc32(p)) for p in pk], dtype=np.uint32)
     assert np.array_equal(mine, ref)
+
+
+def test_streams_out_of_lock_step(oracle, cuda):
+    """Slots that start late, run at their own pace, end and are reused (vbm_frontend_write_streams /
+    _restart_streams): every logical stream still equals the oracle run on its own."""
+    import vorbis_aotuv_lancer_amd as v
+    ch, rate, q = 2, 44100, 0.5
+    osetup = orc.Setup(oracle, ch, rate, q)
+
+    def oracle_stream(sig):
+        st = orc.Stream(osetup)
+        oracle.lib.orc_stream_set_capture(st.v, 0)
+        seq = []
+        for at in range(0, sig.shape[1], 1024):
+            st.write(sig[:, at:at + 1024])
+            seq.extend(st.blocks())
+        st.finish()
+        seq.extend(st.blocks())
+        st.close()
+        return [((b["lW"], b["W"], b["nW"], b["block_mode"], b["eos"], b["granulepos"], b["sequence"]), b["packet"]) for b in seq]
+
+    sig = {name: synth_signal(ch, rate, n * 1024, seed=seed) for name, n, seed in
+           [("a0", 30, 11), ("a1", 45, 12), ("b2", 25, 13), ("b3", 25, 14), ("c0", 12, 15)]}
+    enc = v.Encoder(v.Setup(ch, rate, q), 4)
+    fe = v.FrontEnd(enc)
+    got = [[] for _ in range(4)]
+    logical = {}
+
+    def feed(slots_and_names, chunk):
+        ids, pcs = [], []
+        for slot, name in slots_and_names:
+            if chunk[name] * 1024 < sig[name].shape[1]:
+                ids.append(slot)
+                pcs.append(sig[name][:, chunk[name] * 1024:(chunk[name] + 1) * 1024])
+                chunk[name] += 1
+        if ids:
+            fe.write_streams(ids, torch.from_numpy(np.stack(pcs)).to(cuda).contiguous())
+        drain(fe, got)
+
+    chunk = {k: 0 for k in sig}
+    for _ in range(20):                                    # slots 0, 1 run; slots 2, 3 have never been written
+        feed([(0, "a0"), (1, "a1")], chunk)
+    assert not got[2] and not got[3]
+    fe.restart_streams([2, 3])
+    for _ in range(10):                                    # a0 ends after 30 chunks
+        feed([(0, "a0"), (1, "a1"), (2, "b2"), (3, "b3")], chunk)
+    fe.finish([0])
+    drain(fe, got)
+    logical["a0"], got[0] = got[0], []
+    fe.restart_streams([0])                                # slot 0 is reused
+    for _ in range(15):
+        feed([(0, "c0"), (1, "a1"), (2, "b2"), (3, "b3")], chunk)
+    fe.finish([0, 1, 2, 3])
+    drain(fe, got)
+    logical["c0"], logical["a1"], logical["b2"], logical["b3"] = got
+    for name in sig:
+        assert chunk[name] * 1024 == sig[name].shape[1]
+        assert logical[name] == oracle_stream(sig[name]), f"stream {name} differs from the oracle"

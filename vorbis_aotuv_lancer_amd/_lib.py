@@ -60,6 +60,8 @@ SIGNATURES = {
     "vbm_frontend_reset": (C.c_int, [C.c_void_p]),
     "vbm_frontend_write": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vbm_frontend_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "vbm_frontend_write_streams": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "vbm_frontend_restart_streams": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vbm_frontend_max_buffered": (C.c_int, [C.c_void_p]),
     "vbm_frontend_capacity": (C.c_int, [C.c_void_p]),
     "vbm_frontend_encode_round": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]),

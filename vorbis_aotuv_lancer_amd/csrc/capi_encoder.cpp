@@ -330,6 +330,12 @@ extern "C" int vbm_encoder_reset(vbm_encoder *e)
     return VBM_OK;
 }
 
+// the listed streams start over (a new stream in a used slot); d_ids: device copy of the ids
+int vbm_encoder_reset_streams_dev(vbm_encoder *e, const int *d_ids, int n, hipStream_t q)
+{
+    return vbm_launch_reset_streams(&e->bw[0].st, d_ids, n, q) ? VBM_EHIP : VBM_OK;
+}
+
 static void configure(vbm_encoder *e, vbm_batch &b, int block_mode, int nsb, const float *d_pcm, int w)
 {
     b = e->bw[w];

@@ -19,6 +19,7 @@
 
 vbm_setup_host *vbm_encoder_setup_host(vbm_encoder *e);
 int vbm_encoder_streams(const vbm_encoder *e);
+int vbm_encoder_reset_streams_dev(vbm_encoder *e, const int *d_ids, int n, hipStream_t q);
 
 struct vbm_frontend {
     vbm_encoder *enc;
@@ -199,6 +200,77 @@ extern "C" int vbm_frontend_write(vbm_frontend *fe, const float *d_pcm, int vals
     fe->dirty = true;
     fe->pending_steps += vals / 64 + 1;
     if (cross) fe->pending_steps += (bs1 / 2 + bs1) / 64;   // the first search starts at step 0
+    return VBM_OK;
+}
+
+static int upload_ids(vbm_frontend *fe, const int *stream_ids, int n, hipStream_t st)
+{
+    for (int i = 0; i < n; i++)
+        if (stream_ids[i] < 0 || stream_ids[i] >= fe->S) return VBM_EINVAL;
+    (void)hipStreamSynchronize(st);   // h_ids is reused by the rounds
+    memcpy(fe->h_ids, stream_ids, n * sizeof(int));
+    hipError_t err = hipMemcpyAsync(fe->d_ids, fe->h_ids, n * sizeof(int), hipMemcpyHostToDevice, st);
+    return err == hipSuccess ? VBM_OK : vbm_set_hip_error(err, "hipMemcpyAsync(stream ids)");
+}
+
+// vorbis_analysis_buffer + vorbis_analysis_wrote for a subset of the streams: d_pcm [n][ch][vals]
+extern "C" int vbm_frontend_write_streams(vbm_frontend *fe, const int *stream_ids, int n, const float *d_pcm, int vals,
+                                          void *stream)
+{
+    if (!fe || n < 0 || (n && (!stream_ids || !d_pcm)) || vals <= 0) return VBM_EINVAL;
+    if (n == 0) return VBM_OK;
+    const vbm_setup *s = fe->hs;
+    const int bs1 = s->blocksizes[1];
+    if (vals > 2 * bs1) return VBM_EINVAL;
+    std::vector<char> seen(fe->S, 0);
+    for (int k = 0; k < n; k++) {
+        const int i = stream_ids[k];
+        if (i < 0 || i >= fe->S || seen[i]) return VBM_EINVAL;   // a stream once per call
+        seen[i] = 1;
+        if (fe->ended[i]) { g_vbm_err = "vbm_frontend_write_streams after vbm_frontend_finish"; return VBM_EINVAL; }
+        if (fe->pcm_current[i] + vals > fe->f.cap - 3 * bs1) {
+            g_vbm_err = "PCM buffer full: drain blocks with vbm_frontend_encode_round before writing more";
+            return VBM_EINVAL;
+        }
+    }
+    hipStream_t st = (hipStream_t)stream;
+    int rc = upload_ids(fe, stream_ids, n, st);
+    if (rc) return rc;
+    if (vbm_fe_launch_append_ids(&fe->f, fe->d_ids, n, d_pcm, vals, s->pre_amplitude, st)) return VBM_EHIP;
+    bool cross = false;
+    for (int k = 0; k < n; k++) {
+        const int i = stream_ids[k];
+        fe->pcm_current[i] += vals;
+        if (!fe->started[i] && fe->pcm_current[i] - bs1 / 2 > bs1) { fe->started[i] = 1; cross = true; }
+    }
+    if (cross && vbm_fe_launch_extrapolate(&fe->f, nullptr, 0, 0, bs1, st)) return VBM_EHIP;
+    (void)hipStreamSynchronize(st);   // d_ids / h_ids are free again
+    fe->dirty = true;
+    fe->pending_steps += vals / 64 + 1;
+    if (cross) fe->pending_steps += (bs1 / 2 + bs1) / 64;
+    return VBM_OK;
+}
+
+// a new stream starts in each of the listed slots (vorbis_analysis_init state for front end and encoder)
+extern "C" int vbm_frontend_restart_streams(vbm_frontend *fe, const int *stream_ids, int n, void *stream)
+{
+    if (!fe || n < 0 || (n && !stream_ids)) return VBM_EINVAL;
+    if (n == 0) return VBM_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int bs1 = fe->hs->blocksizes[1];
+    int rc = upload_ids(fe, stream_ids, n, st);
+    if (rc) return rc;
+    if (vbm_fe_launch_restart(&fe->f, fe->d_ids, n, bs1, st)) return VBM_EHIP;
+    rc = vbm_encoder_reset_streams_dev(fe->enc, fe->d_ids, n, st);
+    if (rc) return rc;
+    (void)hipStreamSynchronize(st);
+    for (int k = 0; k < n; k++) {
+        const int i = stream_ids[k];
+        fe->pcm_current[i] = bs1 / 2;
+        fe->W[i] = 0;
+        fe->started[i] = 0;
+        fe->ended[i] = 0;
+    }
     return VBM_OK;
 }
 

@@ -49,6 +49,53 @@ __global__ void k_fe_commit(vbm_fe_state f, int vals)
     if (s < f.S) f.pcm_current[s] += vals;
 }
 
+// the same for a subset of the streams: src holds [k][ch][vals] for stream ids[k]
+__global__ void k_fe_append_ids(vbm_fe_state f, const int *__restrict__ ids, const float *__restrict__ src, int vals,
+                                float pre_amplitude)
+{
+    const int kc = blockIdx.x;                      // listed stream k, channel c
+    const int k = kc / f.ch, c = kc % f.ch;
+    const int s = ids[k];
+    float *dst = f.pcm + (long)f.parity[s] * f.plane + ((long)s * f.ch + c) * f.cap + f.pcm_current[s];
+    const float *in = src + (long)kc * vals;
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < vals; i += gridDim.y * blockDim.x)
+        dst[i] = in[i] * pre_amplitude;
+}
+
+__global__ void k_fe_commit_ids(vbm_fe_state f, const int *__restrict__ ids, int n, int vals)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) f.pcm_current[ids[k]] += vals;
+}
+
+// vorbis_analysis_init state for the listed streams (a new stream starts in a used slot): lib/block.c:306-344,
+// _ve_envelope_init lib/envelope.c:42-87.  One lane per (listed stream, channel); channel 0 also resets the
+// per-stream scalars and marks.
+__global__ void k_fe_restart(vbm_fe_state f, const int *__restrict__ ids, int n, int long_n)
+{
+    const int lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= n * f.ch) return;
+    const int s = ids[lane / f.ch], ci = lane % f.ch;
+    const long SC = (long)f.S * f.ch, c = (long)s * f.ch + ci;
+    // the reference's buffer starts zeroed: the first centerW samples are silence until they are extrapolated
+    float *pcm = f.pcm + (long)f.parity[s] * f.plane + c * f.cap;
+    for (int i = 0; i < long_n / 2; i++) pcm[i] = 0.f;
+    for (int k = 0; k < VBM_VE_AMP; k++)
+        for (int jb = 0; jb < 16; jb++) f.ve_ampbuf[((long)k * SC + c) * 16 + jb] = 0.f;
+    for (int jb = 0; jb < 16; jb++) f.ve_ampptr[c * 16 + jb] = 0;
+    for (int k = 0; k < VBM_VE_NEARDC; k++) f.ve_nearDC[(long)k * SC + c] = 0.f;
+    f.ve_nearacc[c] = 0.f;
+    f.ve_nearacc[SC + c] = 0.f;
+    f.ve_nearptr[c] = 0;
+    if (ci == 0) {
+        f.pcm_current[s] = long_n / 2; f.centerW[s] = long_n / 2;
+        f.lW[s] = 0; f.W[s] = 0; f.nW[s] = 0; f.eofflag[s] = 0; f.preextrapolate[s] = 0;
+        f.granulepos[s] = 0; f.sequence[s] = 3;
+        f.ve_current[s] = 0; f.ve_cursor[s] = long_n / 2; f.ve_curmark[s] = -1; f.ve_stretch[s] = 0;
+        for (int k = 0; k < f.marks; k++) f.ve_mark[(long)k * f.S + s] = 0;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // vorbis_lpc_from_data (lib/lpc.c:60-130).  data(i) is an accessor; M = order
 template <int M, typename Acc>
@@ -542,6 +589,24 @@ extern "C" int vbm_fe_launch_append(const vbm_fe_state *f, const float *d_src, i
     const unsigned gx = (unsigned)((vals + 255) / 256);
     hipLaunchKernelGGL(k_fe_append, dim3((unsigned)(f->S * f->ch), gx ? gx : 1), dim3(256), 0, st, *f, d_src, vals, pre_amplitude);
     hipLaunchKernelGGL(k_fe_commit, dim3((unsigned)((f->S + 255) / 256)), dim3(256), 0, st, *f, vals);
+    return CHECK_LAUNCH();
+}
+
+extern "C" int vbm_fe_launch_append_ids(const vbm_fe_state *f, const int *d_ids, int n, const float *d_src, int vals,
+                                        float pre_amplitude, hipStream_t st)
+{
+    if (n <= 0) return 0;
+    const unsigned gy = (unsigned)((vals + 255) / 256);
+    hipLaunchKernelGGL(k_fe_append_ids, dim3((unsigned)(n * f->ch), gy ? gy : 1), dim3(256), 0, st, *f, d_ids, d_src, vals,
+                       pre_amplitude);
+    hipLaunchKernelGGL(k_fe_commit_ids, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, *f, d_ids, n, vals);
+    return CHECK_LAUNCH();
+}
+
+extern "C" int vbm_fe_launch_restart(const vbm_fe_state *f, const int *d_ids, int n, int long_n, hipStream_t st)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_fe_restart, dim3((unsigned)((n * f->ch + 63) / 64)), dim3(64), 0, st, *f, d_ids, n, long_n);
     return CHECK_LAUNCH();
 }
 

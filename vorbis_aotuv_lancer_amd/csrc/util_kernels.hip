@@ -67,7 +67,34 @@ int from_tiled(const T *src, T *dst, int ncols, int rows, size_t slab, hipStream
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// carried encoder state of the listed streams back to its initial values (vorbis_analysis_init,
+// lib/block.c:306-344; _vp_global_look ampmax -9999): one lane per (listed stream, channel)
+__global__ void k_reset_streams(vbm_stream_state st, const int *__restrict__ ids, int n)
+{
+    const int lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= n * st.ch) return;
+    const int s = ids[lane / st.ch], ci = lane % st.ch;
+    const int col = s * st.ch + ci;
+    float *mb = st.mblock + (size_t)(col >> 6) * st.slab_words + (col & 63);
+    for (int i = 0; i < 2048 + 256; i++) mb[(size_t)i * 64] = 0.f;   // mblock rows, then tblock rows
+    st.lowcomp[col] = 0.f;
+    if (ci == 0) {
+        st.g_ampmax[s] = -9999.f;
+        st.vbi_ampmax[s] = -9999.f;
+        st.lW_block_mode[s] = 0;
+        st.lW_no[s] = 0;
+        st.impadnum[s] = 0;
+    }
+}
+
 }  // namespace
+
+extern "C" int vbm_launch_reset_streams(const vbm_stream_state *st, const int *d_ids, int n, hipStream_t q)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_reset_streams, dim3((unsigned)((n * st->ch + 63) / 64)), dim3(64), 0, q, *st, d_ids, n);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 
 extern "C" int vbm_launch_spread_flags(const vbm_batch *b, hipStream_t st)
 {

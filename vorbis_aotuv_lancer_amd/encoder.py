@@ -158,6 +158,23 @@ class FrontEnd:
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         check(lib.vbm_frontend_write(self._h, pcm.data_ptr(), int(pcm.shape[2]), st), "vbm_frontend_write")
 
+    def write_streams(self, stream_ids, pcm):
+        """pcm: CUDA float32 [len(stream_ids), channels, vals] — new samples for the listed streams only."""
+        ids = np.ascontiguousarray(stream_ids, dtype=np.int32)
+        ch = self.enc.setup.channels
+        if not (pcm.is_cuda and pcm.dtype == torch.float32 and pcm.is_contiguous() and pcm.dim() == 3
+                and pcm.shape[0] == len(ids) and pcm.shape[1] == ch):
+            raise ValueError(f"pcm must be a contiguous CUDA float32 tensor of shape ({len(ids)}, {ch}, vals)")
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(lib.vbm_frontend_write_streams(self._h, ids.ctypes.data, len(ids), pcm.data_ptr(), int(pcm.shape[2]), st),
+              "vbm_frontend_write_streams")
+
+    def restart_streams(self, stream_ids):
+        """a new stream starts in each listed slot"""
+        ids = np.ascontiguousarray(stream_ids, dtype=np.int32)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(lib.vbm_frontend_restart_streams(self._h, ids.ctypes.data, len(ids), st), "vbm_frontend_restart_streams")
+
     def finish(self, stream_ids=None):
         """vorbis_analysis_wrote(vd, 0) for the listed streams (default: all)."""
         ids = np.arange(self.enc.nstreams, dtype=np.int32) if stream_ids is None else \
