@@ -285,11 +285,10 @@ const unsigned char *orc_block_packet(const orc_block *vb, long *bytes)
 }
 
 /* ---- survey probe: signal + driver of SURVEY.md Appendix B ----------------------------- */
-static unsigned probe_lcg;
-static float probe_rnd(void)
+static float probe_rnd(unsigned *lcg)          /* state is the caller's: the probe runs one stream per thread */
 {
-    probe_lcg = probe_lcg * 1664525u + 1013904223u;
-    return ((probe_lcg >> 8) & 0xffff) / 32768.f - 1.f;
+    *lcg = *lcg * 1664525u + 1013904223u;
+    return ((*lcg >> 8) & 0xffff) / 32768.f - 1.f;
 }
 
 long orc_encode_probe(const orc_setup *s, int secs, const char *out_path, double *seconds_spent)
@@ -301,7 +300,7 @@ long orc_encode_probe(const orc_setup *s, int secs, const char *out_path, double
     int ch = s->channels, i, c;
     struct timespec t0, t1;
     float *b[ORC_MAXCH];
-    probe_lcg = 12345u;
+    unsigned probe_lcg = 12345u;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     while (1) {
         if (pos >= total) {
@@ -314,8 +313,8 @@ long orc_encode_probe(const orc_setup *s, int secs, const char *out_path, double
                 int burst = (((pos + i) / (rate / 3)) % 4 == 3) && ((pos + i) % (rate / 3)) < 200;
                 for (c = 0; c < ch; c++) {
                     float smp = 0.3f * sin(2 * M_PI * 440.0 * (c + 1) * t) + 0.2f * sin(2 * M_PI * 3000.0 * t + c) +
-                                0.05f * probe_rnd();
-                    if (burst) smp += 0.6f * probe_rnd();
+                                0.05f * probe_rnd(&probe_lcg);
+                    if (burst) smp += 0.6f * probe_rnd(&probe_lcg);
                     b[c][i] = smp;
                 }
             }
@@ -350,14 +349,14 @@ void orc_probe_signal(int ch, long rate, long nsamples, float *out)
 {
     long i;
     int c;
-    probe_lcg = 12345u;
+    unsigned probe_lcg = 12345u;
     for (i = 0; i < nsamples; i++) {
         double t = (double)i / rate;
         int burst = ((i / (rate / 3)) % 4 == 3) && (i % (rate / 3)) < 200;
         for (c = 0; c < ch; c++) {
             float smp = 0.3f * sin(2 * M_PI * 440.0 * (c + 1) * t) + 0.2f * sin(2 * M_PI * 3000.0 * t + c) +
-                        0.05f * probe_rnd();
-            if (burst) smp += 0.6f * probe_rnd();
+                        0.05f * probe_rnd(&probe_lcg);
+            if (burst) smp += 0.6f * probe_rnd(&probe_lcg);
             out[c * nsamples + i] = smp;
         }
     }
