@@ -55,6 +55,7 @@ void orc_bits_reset(orc_bits *b);
 void orc_bits_clear(orc_bits *b);
 void orc_bits_write(orc_bits *b, unsigned long value, int bits);
 long orc_bits_bytes(const orc_bits *b);
+void orc_bits_writetrunc(orc_bits *b, long bits);
 
 /* ---- MDCT (lib/mdct.c, lib/mdct.h:55-73) ------------------------------------------- */
 typedef struct {
@@ -222,6 +223,10 @@ typedef struct orc_setup {
     int block_lowpassr[2];
     float pre_amplitude;
     int modebits;
+    /* bitrate_manager_info (lib/bitrate.h:41-50); managed = hi.managed (lib/vorbisenc.c:1037) */
+    int managed;
+    long bi_avg_rate, bi_min_rate, bi_max_rate, bi_reservoir_bits;
+    double bi_reservoir_bias, bi_slew_damp;
     /* looks built once (lib/block.c:181-303) */
     orc_mdct mdct[2];
     orc_drft fft[2];
@@ -255,6 +260,7 @@ void orc_couple_quantize_normalize(const orc_setup *s, int blobno, const orc_psy
                                    int sliding_lowpass, int ch, int lowpassr);
 /* floor1_fit: returns 1 and fills post[] if a floor was fit, 0 for "no floor" (NULL in the reference) */
 int orc_floor1_fit(const orc_floor *look, const float *logmdct, const float *logmask, int *post);
+int orc_floor1_interpolate_fit(const orc_floor *look, const int *A, const int *B, int del, int *output);
 int orc_floor1_encode(const orc_setup *s, orc_bits *opb, const orc_floor *look, int *post /* may be NULL */,
                       int *ilogmask, int n_half);
 /* residue: partword arrays are caller allocated [ch][partvals] */
@@ -282,7 +288,10 @@ typedef struct orc_block {
     float ampmax;
     int blocktype;
     float *pcmbuf[ORC_MAXCH]; /* n floats per channel (window of the block) */
-    orc_bits opb;
+    orc_bits opb;                        /* the packet handed out (VBR: blob PACKETBLOBS/2 is written here directly) */
+    orc_bits blob[ORC_PACKETBLOBS];      /* managed mode: vbi->packetblob[] */
+    int blob_bytes[ORC_PACKETBLOBS];     /* sizes before the bitrate manager truncates / pads the chosen one */
+    int choice;                          /* bm->choice of this block */
     /* captured intermediates of the last orc_analysis() (stage goldens for kernel tests) */
     float *cap_windowed[ORC_MAXCH], *cap_gmdct_raw[ORC_MAXCH], *cap_gmdct[ORC_MAXCH], *cap_logfft[ORC_MAXCH],
         *cap_logmdct[ORC_MAXCH], *cap_noise[ORC_MAXCH], *cap_tone[ORC_MAXCH], *cap_logmask[ORC_MAXCH],
@@ -314,6 +323,10 @@ typedef struct orc_stream {
     int *ve_mark;
     long ve_storage, ve_current, ve_curmark, ve_cursor;
     int capture; /* keep stage intermediates in blocks */
+    /* bitrate_manager_state, lib/bitrate.h:25-39 */
+    int bm_managed;
+    long bm_avg_reservoir, bm_minmax_reservoir, bm_avg_bitsper, bm_min_bitsper, bm_max_bitsper, bm_short_per_long;
+    double bm_avgfloat;
 } orc_stream;
 
 orc_stream *orc_stream_new(const orc_setup *s);
@@ -325,6 +338,10 @@ int orc_analysis_wrote(orc_stream *v, int vals);
 int orc_analysis_blockout(orc_stream *v, orc_block *vb); /* 1 = block ready */
 int orc_analysis(orc_stream *v, orc_block *vb);          /* vorbis_analysis + VBR bitrate hand-off */
 const unsigned char *orc_block_packet(const orc_block *vb, long *bytes);
+/* managed mode: choice made by the bitrate manager and the 15 blob sizes it chose from */
+int orc_block_choice(const orc_block *vb, int *blob_bytes /* [ORC_PACKETBLOBS] or NULL */);
+const unsigned char *orc_block_blob(const orc_block *vb, int k, long *bytes);
+void orc_stream_bitrate_state(const orc_stream *v, int64_t *out /* avg_reservoir, minmax_reservoir */, double *avgfloat);
 void orc_block_info64(const orc_block *vb, int64_t *out); /* granulepos, sequence */
 
 /* survey probe signal + driver: encodes `secs` seconds of the synthetic

@@ -65,6 +65,17 @@ void orc_bits_write(orc_bits *b, unsigned long value, int bits)
 
 long orc_bits_bytes(const orc_bits *b) { return b->endbyte + (b->endbit + 7) / 8; }
 
+/* libogg oggpack_writetrunc: cut the buffer back to `bits` bits, clearing the bits above in the last byte */
+void orc_bits_writetrunc(orc_bits *b, long bits)
+{
+    long bytes = bits >> 3;
+    if (!b->buf) return;
+    bits -= bytes * 8;
+    b->endbyte = bytes;
+    b->endbit = (int)bits;
+    b->buf[bytes] &= (unsigned char)((1u << bits) - 1);
+}
+
 /* ---- books ------------------------------------------------------------------------- */
 int orc_ilog(uint32_t v)
 {

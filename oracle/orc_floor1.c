@@ -227,6 +227,19 @@ static int post_Y(int *A, int *B, int pos)
     return (A[pos] + B[pos]) >> 1;
 }
 
+/* lib/floor1.c:752-771: 16.16 fixed-point blend of two fits; 0 (NULL) unless both exist */
+int orc_floor1_interpolate_fit(const orc_floor *look, const int *A, const int *B, int del, int *output)
+{
+    long i;
+    long posts = look->posts;
+    if (!A || !B) return 0;
+    for (i = 0; i < posts; i++) {
+        output[i] = ((65536 - del) * (A[i] & 0x7fff) + del * (B[i] & 0x7fff) + 32768) >> 16;
+        if (A[i] & 0x8000 && B[i] & 0x8000) output[i] |= 0x8000;
+    }
+    return 1;
+}
+
 int orc_floor1_fit(const orc_floor *look, const float *logmdct, const float *logmask, int *output)
 {
     long i, j;

@@ -1,7 +1,8 @@
 /* ORACLE — test infrastructure only.
  *
  * Per-block pipeline orchestration, restating mapping0_forward (lib/mapping0.c:738-1322,
- * scalar branches, VBR i.e. packetblob PACKETBLOBS/2 only):
+ * scalar branches; VBR = packetblob PACKETBLOBS/2 only, managed bitrate = all PACKETBLOBS with the
+ * two extra mask fits :1097-1168 and the interpolated fits :1169-1181):
  *   loop A :783-902   post-noise flag, window, MDCT, FFT, logfft + ampmax
  *   loop B :908-1182  logmdct, loudnoise fix, noise mask, tone mask, offset+mix, floor fit
  *   loop C :1204-1313 packet header bits, floor encode, couple/quantise, residue class+forward,
@@ -48,8 +49,10 @@ int orc_mapping0_forward(orc_stream *v, orc_block *vb)
     float poste[ORC_MAXCH];
     float *gmdct[ORC_MAXCH], *epeak[ORC_MAXCH], *npeak[ORC_MAXCH];
     int *iwork[ORC_MAXCH];
-    int floor_posts[ORC_MAXCH][ORC_VIF_POSIT + 2];
-    int floor_valid[ORC_MAXCH];
+    int floor_posts[ORC_MAXCH][ORC_PACKETBLOBS][ORC_VIF_POSIT + 2];
+    int floor_valid[ORC_MAXCH][ORC_PACKETBLOBS]; /* 0 = the reference's NULL post vector (:930-931) */
+    const int managed = v->bm_managed;
+    const int MID = ORC_PACKETBLOBS / 2;
 
     float global_ampmax = vb->ampmax;
     float local_ampmax[ORC_MAXCH];
@@ -132,7 +135,8 @@ int orc_mapping0_forward(orc_stream *v, orc_block *vb)
             orc_tonemask(psy_look, logfft, tone, global_ampmax, local_ampmax[i]);
             if (v->capture) memcpy(vb->cap_tone[i], tone, n / 2 * sizeof(float));
 
-            orc_offset_and_mix(s, psy_look, noise, tone, 1, 0, logmask, mdct, logmdct, lastmdct, tempmdct,
+            memset(floor_valid[i], 0, sizeof(floor_valid[i]));
+            orc_offset_and_mix(s, psy_look, noise, tone, 1, managed, logmask, mdct, logmdct, lastmdct, tempmdct,
                                *lowcomp, nepeak, vif->info_n, block_mode, vb->nW, v->lW_block_mode, v->lW_no,
                                v->impadnum);
             if (v->capture) {
@@ -140,10 +144,36 @@ int orc_mapping0_forward(orc_stream *v, orc_block *vb)
                 memcpy(vb->cap_gmdct[i], mdct, n / 2 * sizeof(float));
             }
 
-            floor_valid[i] = orc_floor1_fit(&s->floor[info->floorsubmap[submap]], logmdct, logmask, floor_posts[i]);
+            floor_valid[i][MID] =
+                orc_floor1_fit(&s->floor[info->floorsubmap[submap]], logmdct, logmask, floor_posts[i][MID]);
             if (v->capture) {
-                vb->cap_post_valid[i] = floor_valid[i];
-                memcpy(vb->cap_post[i], floor_posts[i], sizeof(floor_posts[i]));
+                vb->cap_post_valid[i] = floor_valid[i][MID];
+                memcpy(vb->cap_post[i], floor_posts[i][MID], sizeof(floor_posts[i][MID]));
+            }
+
+            /* lib/mapping0.c:1097-1181: two more fits (hi/lo rate) and the interpolated ones between */
+            if (managed && floor_valid[i][MID]) {
+                const orc_floor *fl = &s->floor[info->floorsubmap[submap]];
+                orc_offset_and_mix(s, psy_look, noise, tone, 2, managed, logmask, mdct, logmdct, lastmdct, tempmdct,
+                                   *lowcomp, nepeak, vif->info_n, block_mode, vb->nW, v->lW_block_mode, v->lW_no,
+                                   v->impadnum);
+                floor_valid[i][ORC_PACKETBLOBS - 1] =
+                    orc_floor1_fit(fl, logmdct, logmask, floor_posts[i][ORC_PACKETBLOBS - 1]);
+
+                orc_offset_and_mix(s, psy_look, noise, tone, 0, managed, logmask, mdct, logmdct, lastmdct, tempmdct,
+                                   *lowcomp, nepeak, vif->info_n, block_mode, vb->nW, v->lW_block_mode, v->lW_no,
+                                   v->impadnum);
+                floor_valid[i][0] = orc_floor1_fit(fl, logmdct, logmask, floor_posts[i][0]);
+
+                for (k = 1; k < MID; k++)
+                    floor_valid[i][k] = orc_floor1_interpolate_fit(
+                        fl, floor_valid[i][0] ? floor_posts[i][0] : NULL, floor_posts[i][MID], k * 65536 / MID,
+                        floor_posts[i][k]);
+                for (k = MID + 1; k < ORC_PACKETBLOBS - 1; k++)
+                    floor_valid[i][k] = orc_floor1_interpolate_fit(
+                        fl, floor_posts[i][MID],
+                        floor_valid[i][ORC_PACKETBLOBS - 1] ? floor_posts[i][ORC_PACKETBLOBS - 1] : NULL,
+                        (k - MID) * 65536 / MID, floor_posts[i][k]);
             }
         }
         free(noise);
@@ -156,8 +186,12 @@ int orc_mapping0_forward(orc_stream *v, orc_block *vb)
     {
         int *couple_bundle[ORC_MAXCH];
         int zerobundle[ORC_MAXCH];
-        orc_bits *opb = &vb->opb;
-        k = ORC_PACKETBLOBS / 2;
+
+        /* once for VBR, PACKETBLOBS times for managed bitrate (lib/mapping0.c:1204-1206); note that the
+         * aoTuV block-state update at the end sits INSIDE this loop in the reference (:1296-1304) */
+        for (k = (managed ? 0 : MID); k <= (managed ? ORC_PACKETBLOBS - 1 : MID); k++) {
+        orc_bits *opb = managed ? &vb->blob[k] : &vb->opb;
+        const int capture = v->capture && k == MID;
 
         orc_bits_write(opb, 0, 1);
         orc_bits_write(opb, modenumber, s->modebits);
@@ -170,13 +204,13 @@ int orc_mapping0_forward(orc_stream *v, orc_block *vb)
             int submap = info->chmuxlist[i];
             int *ilogmask = iwork[i];
             nonzero[i] = orc_floor1_encode(s, opb, &s->floor[info->floorsubmap[submap]],
-                                           floor_valid[i] ? floor_posts[i] : NULL, ilogmask, n / 2);
-            if (v->capture) memcpy(vb->cap_ilogmask[i], ilogmask, n / 2 * sizeof(int));
+                                           floor_valid[i][k] ? floor_posts[i][k] : NULL, ilogmask, n / 2);
+            if (capture) memcpy(vb->cap_ilogmask[i], ilogmask, n / 2 * sizeof(int));
         }
 
         orc_couple_quantize_normalize(s, k, psy_look, info, gmdct, epeak, npeak, iwork, nonzero,
                                       s->psy_g.sliding_lowpass[vb->W][k], ch, lowpass_residue);
-        if (v->capture)
+        if (capture)
             for (i = 0; i < ch; i++) {
                 memcpy(vb->cap_residue[i], iwork[i], n / 2 * sizeof(int));
                 memcpy(vb->cap_epeak[i], epeak[i], n / 2 * sizeof(float));
@@ -217,6 +251,7 @@ int orc_mapping0_forward(orc_stream *v, orc_block *vb)
         if (v->lW_block_mode == block_mode) v->lW_no++;
         else v->lW_no = 1;
         v->lW_block_mode = block_mode;
+        }
     }
 
     for (i = 0; i < ch; i++) {

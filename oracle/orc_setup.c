@@ -445,6 +445,15 @@ orc_setup *orc_setup_load(const char *common_vpk, const char *mode_vpk)
         s->block_lowpassr[1] = lp[1];
     }
     s->pre_amplitude = *(const float *)need(fm, "hi/pre_amplitude", VPK_F32, &n);
+    s->managed = *(const int *)need(fm, "info/managed", VPK_I32, &n);
+    if (s->managed) { /* lib/vorbisenc.c:890-901 */
+        const int64_t *r = (const int64_t *)need(fm, "bi/rates", VPK_I64, &n);
+        const double *d = (const double *)need(fm, "bi/floats", VPK_F64, &n);
+        s->bi_avg_rate = (long)r[0]; s->bi_min_rate = (long)r[1]; s->bi_max_rate = (long)r[2];
+        s->bi_reservoir_bits = (long)r[3];
+        s->bi_reservoir_bias = d[0];
+        s->bi_slew_damp = d[1];
+    }
     if (s->channels > ORC_MAXCH || s->floors > 4 || s->residues > 4 || s->psys > 4 || s->modes > 2) {
         fprintf(stderr, "oracle: setup exceeds static limits\n");
         abort();

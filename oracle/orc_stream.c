@@ -41,6 +41,22 @@ orc_stream *orc_stream_new(const orc_setup *s)
     v->ve_mark = (int *)calloc(v->ve_storage, sizeof(int));
     v->ve_cursor = s->blocksizes[1] / 2;
     v->sequence = 3;
+    /* vorbis_bitrate_init, lib/bitrate.c:28-56 */
+    if (s->managed && s->bi_reservoir_bits > 0) {
+        long ratesamples = s->rate;
+        int halfsamples = (int)(s->blocksizes[0] >> 1);
+        v->bm_short_per_long = s->blocksizes[1] / s->blocksizes[0];
+        v->bm_managed = 1;
+        v->bm_avg_bitsper = rint(1. * s->bi_avg_rate * halfsamples / ratesamples);
+        v->bm_min_bitsper = rint(1. * s->bi_min_rate * halfsamples / ratesamples);
+        v->bm_max_bitsper = rint(1. * s->bi_max_rate * halfsamples / ratesamples);
+        v->bm_avgfloat = ORC_PACKETBLOBS / 2;
+        {
+            long desired_fill = s->bi_reservoir_bits * s->bi_reservoir_bias;
+            v->bm_minmax_reservoir = desired_fill;
+            v->bm_avg_reservoir = desired_fill;
+        }
+    }
     return v;
 }
 
@@ -75,6 +91,8 @@ orc_block *orc_block_new(const orc_setup *s)
         b->cap_residue[i] = (int *)calloc(n / 2, sizeof(int));
     }
     orc_bits_init(&b->opb);
+    for (i = 0; i < ORC_PACKETBLOBS; i++) orc_bits_init(&b->blob[i]);
+    b->choice = ORC_PACKETBLOBS / 2;
     return b;
 }
 
@@ -89,6 +107,7 @@ void orc_block_free(orc_block *b)
         free(b->cap_residue[i]);
     }
     orc_bits_clear(&b->opb);
+    for (i = 0; i < ORC_PACKETBLOBS; i++) orc_bits_clear(&b->blob[i]);
     free(b);
 }
 
@@ -272,10 +291,150 @@ int orc_analysis_blockout(orc_stream *v, orc_block *vb)
     return (1);
 }
 
+/* vorbis_bitrate_addblock, managed branch (lib/bitrate.c:98-226): pick one of the PACKETBLOBS packets of
+ * this block from the running reservoirs, truncate or zero-pad it, update the reservoirs */
+static void bitrate_addblock(orc_stream *v, orc_block *vb)
+{
+    const orc_setup *s = v->s;
+    int choice = rint(v->bm_avgfloat);
+    long this_bits = orc_bits_bytes(&vb->blob[choice]) * 8;
+    long min_target_bits = (vb->W ? v->bm_min_bitsper * v->bm_short_per_long : v->bm_min_bitsper);
+    long max_target_bits = (vb->W ? v->bm_max_bitsper * v->bm_short_per_long : v->bm_max_bitsper);
+    int samples = (int)(s->blocksizes[vb->W] >> 1);
+    long desired_fill = s->bi_reservoir_bits * s->bi_reservoir_bias;
+
+    if (v->bm_avg_bitsper > 0) {
+        double slew = 0.;
+        long avg_target_bits = (vb->W ? v->bm_avg_bitsper * v->bm_short_per_long : v->bm_avg_bitsper);
+        double slewlimit = 15. / s->bi_slew_damp;
+
+        if (v->bm_avg_reservoir + (this_bits - avg_target_bits) > desired_fill) {
+            while (choice > 0 && this_bits > avg_target_bits &&
+                   v->bm_avg_reservoir + (this_bits - avg_target_bits) > desired_fill) {
+                choice--;
+                this_bits = orc_bits_bytes(&vb->blob[choice]) * 8;
+            }
+        } else if (v->bm_avg_reservoir + (this_bits - avg_target_bits) < desired_fill) {
+            while (choice + 1 < ORC_PACKETBLOBS && this_bits < avg_target_bits &&
+                   v->bm_avg_reservoir + (this_bits - avg_target_bits) < desired_fill) {
+                choice++;
+                this_bits = orc_bits_bytes(&vb->blob[choice]) * 8;
+            }
+        }
+
+        slew = rint(choice - v->bm_avgfloat) / samples * s->rate;
+        if (slew < -slewlimit) slew = -slewlimit;
+        if (slew > slewlimit) slew = slewlimit;
+        choice = rint(v->bm_avgfloat += slew / s->rate * samples);
+        this_bits = orc_bits_bytes(&vb->blob[choice]) * 8;
+    }
+
+    if (v->bm_min_bitsper > 0) {
+        if (this_bits < min_target_bits) {
+            while (v->bm_minmax_reservoir - (min_target_bits - this_bits) < 0) {
+                choice++;
+                if (choice >= ORC_PACKETBLOBS) break;
+                this_bits = orc_bits_bytes(&vb->blob[choice]) * 8;
+            }
+        }
+    }
+
+    if (v->bm_max_bitsper > 0) {
+        if (this_bits > max_target_bits) {
+            while (v->bm_minmax_reservoir + (this_bits - max_target_bits) > s->bi_reservoir_bits) {
+                choice--;
+                if (choice < 0) break;
+                this_bits = orc_bits_bytes(&vb->blob[choice]) * 8;
+            }
+        }
+    }
+
+    if (choice < 0) {
+        long maxsize = (max_target_bits + (s->bi_reservoir_bits - v->bm_minmax_reservoir)) / 8;
+        vb->choice = choice = 0;
+        if (orc_bits_bytes(&vb->blob[choice]) > maxsize) {
+            orc_bits_writetrunc(&vb->blob[choice], maxsize * 8);
+            this_bits = orc_bits_bytes(&vb->blob[choice]) * 8;
+        }
+    } else {
+        long minsize = (min_target_bits - v->bm_minmax_reservoir + 7) / 8;
+        if (choice >= ORC_PACKETBLOBS) choice = ORC_PACKETBLOBS - 1;
+        vb->choice = choice;
+        minsize -= orc_bits_bytes(&vb->blob[choice]);
+        while (minsize-- > 0) orc_bits_write(&vb->blob[choice], 0, 8);
+        this_bits = orc_bits_bytes(&vb->blob[choice]) * 8;
+    }
+
+    if (v->bm_min_bitsper > 0 || v->bm_max_bitsper > 0) {
+        if (max_target_bits > 0 && this_bits > max_target_bits) {
+            v->bm_minmax_reservoir += (this_bits - max_target_bits);
+        } else if (min_target_bits > 0 && this_bits < min_target_bits) {
+            v->bm_minmax_reservoir += (this_bits - min_target_bits);
+        } else {
+            if (v->bm_minmax_reservoir > desired_fill) {
+                if (max_target_bits > 0) {
+                    v->bm_minmax_reservoir += (this_bits - max_target_bits);
+                    if (v->bm_minmax_reservoir < desired_fill) v->bm_minmax_reservoir = desired_fill;
+                } else {
+                    v->bm_minmax_reservoir = desired_fill;
+                }
+            } else {
+                if (min_target_bits > 0) {
+                    v->bm_minmax_reservoir += (this_bits - min_target_bits);
+                    if (v->bm_minmax_reservoir > desired_fill) v->bm_minmax_reservoir = desired_fill;
+                } else {
+                    v->bm_minmax_reservoir = desired_fill;
+                }
+            }
+        }
+    }
+
+    if (v->bm_avg_bitsper > 0) {
+        long avg_target_bits = (vb->W ? v->bm_avg_bitsper * v->bm_short_per_long : v->bm_avg_bitsper);
+        v->bm_avg_reservoir += this_bits - avg_target_bits;
+    }
+}
+
+/* vorbis_analysis(vb, NULL) + vorbis_bitrate_addblock + vorbis_bitrate_flushpacket (lib/analysis.c:30-62,
+ * lib/bitrate.c:73-252): the packet of the block is vb->opb afterwards in both modes */
 int orc_analysis(orc_stream *v, orc_block *vb)
 {
+    int i, ret;
     orc_bits_reset(&vb->opb);
-    return orc_mapping0_forward(v, vb);
+    if (v->bm_managed)
+        for (i = 0; i < ORC_PACKETBLOBS; i++) orc_bits_reset(&vb->blob[i]);
+    ret = orc_mapping0_forward(v, vb);
+    if (ret) return ret;
+    vb->choice = ORC_PACKETBLOBS / 2;
+    if (v->bm_managed) {
+        const orc_bits *c;
+        long nb;
+        for (i = 0; i < ORC_PACKETBLOBS; i++) vb->blob_bytes[i] = (int)orc_bits_bytes(&vb->blob[i]);
+        bitrate_addblock(v, vb);
+        c = &vb->blob[vb->choice];
+        nb = orc_bits_bytes(c);
+        for (i = 0; i < nb; i++) orc_bits_write(&vb->opb, c->buf[i], 8);
+    }
+    return 0;
+}
+
+int orc_block_choice(const orc_block *vb, int *blob_bytes)
+{
+    if (blob_bytes) memcpy(blob_bytes, vb->blob_bytes, sizeof(vb->blob_bytes));
+    return vb->choice;
+}
+
+const unsigned char *orc_block_blob(const orc_block *vb, int k, long *bytes)
+{
+    *bytes = orc_bits_bytes(&vb->blob[k]);
+    return vb->blob[k].buf;
+}
+
+void orc_stream_bitrate_state(const orc_stream *v, int64_t *out, double *avgfloat)
+{
+    out[0] = v->bm_avg_reservoir;
+    out[1] = v->bm_minmax_reservoir;
+    *avgfloat = v->bm_avgfloat;
 }
 
 const unsigned char *orc_block_packet(const orc_block *vb, long *bytes)

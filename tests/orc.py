@@ -61,17 +61,27 @@ _DATA = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file_
                       "vorbis_aotuv_lancer_amd", "data")
 
 
+def mode_pack_name(ch, rate, q=None, bitrate=None):
+    if bitrate is None:
+        return f"mode_{ch}ch_{rate}_q{q:g}.vpk"
+    mx, nom, mn = bitrate if isinstance(bitrate, (tuple, list)) else (-1, bitrate, -1)
+    return f"mode_{ch}ch_{rate}_b{nom}" + (f"_max{mx}" if mx > 0 else "") + (f"_min{mn}" if mn > 0 else "") + ".vpk"
+
+
 class Setup:
     """orc_setup for one (channels, rate, quality) class, from the committed mode pack."""
 
-    def __init__(self, oracle, ch, rate, q):
+    def __init__(self, oracle, ch, rate, q=None, bitrate=None):
+        """bitrate = nominal or (max, nominal, min) bits/s selects a managed-bitrate pack
+        (vorbis_encode_init) instead of the VBR one"""
         self.o = oracle
         lib = oracle.lib
         lib.orc_setup_load.restype = C.c_void_p
         lib.orc_setup_load.argtypes = [C.c_char_p, C.c_char_p]
         lib.orc_encode_probe.restype = C.c_long
         lib.orc_encode_probe.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.POINTER(C.c_double)]
-        mode = _os.path.join(_DATA, f"mode_{ch}ch_{rate}_q{q:g}.vpk")
+        mode = _os.path.join(_DATA, mode_pack_name(ch, rate, q, bitrate))
+        self.managed = bitrate is not None
         self.h = lib.orc_setup_load(_os.path.join(_DATA, "common.vpk").encode(), mode.encode())
         if not self.h:
             raise RuntimeError(f"cannot load {mode}")
@@ -180,6 +190,17 @@ class Stream:
             i64 = (C.c_int64 * 2)()
             self.lib.orc_block_info64(self.vb, i64)
             d["granulepos"], d["sequence"] = int(i64[0]), int(i64[1])
+            if self.setup.managed:
+                sizes = (C.c_int * 15)()
+                self.lib.orc_block_choice.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+                d["choice"] = self.lib.orc_block_choice(self.vb, sizes)
+                d["blob_bytes"] = list(sizes)
+                self.lib.orc_block_blob.restype = C.POINTER(C.c_ubyte)
+                self.lib.orc_block_blob.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_long)]
+                d["blobs"] = []
+                for k in range(15):
+                    bp = self.lib.orc_block_blob(self.vb, k, C.byref(nb))
+                    d["blobs"].append(bytes(bp[:min(nb.value, sizes[k])]))
             for name in ("mdct_raw", "mdct", "logfft", "logmdct", "noise", "tone", "logmask", "epeak"):
                 d[name] = np.stack([self._arr(name, c, n, np.float32) for c in range(self.ch)])
             for name in ("ilogmask", "residue"):

@@ -195,7 +195,11 @@ def test_header_packets_read_back_to_the_mode_pack(pack):
     import vorbis_aotuv_lancer_amd as v
     d = vpk.read_vpk(os.path.join(DATA, pack))
     ch, rate, q = int(d["info/channels"][0]), int(d["info/rate"][0]), float(d["info/quality"][0])
-    setup = v.Setup(ch, rate, q)
+    if int(d["info/managed"][0]):
+        av, mn, mx, _ = [int(x) for x in d["bi/rates"]]
+        setup = v.Setup(ch, rate, bitrate=(mx, av, mn))
+    else:
+        setup = v.Setup(ch, rate, q)
     comments = ["TITLE=parity", "ARTIST=" + "x" * 300]
     hdr = v.header_packets(setup, comments)
     u = unpack_headers(*hdr)

@@ -104,8 +104,11 @@ class Template:
             setattr(self, k, x)
 
 
-def get_setup_template(ch, srate, req):
-    """lib/vorbisenc.c:674-713 with q_or_bitrate == 0.  req: python float (double)."""
+def get_setup_template(ch, srate, req, q_or_bitrate=0):
+    """lib/vorbisenc.c:674-713.  req: python float (double); q_or_bitrate 1 = req is a bitrate
+    (divided by the channel count and looked up in rate_mapping)."""
+    if q_or_bitrate:
+        req /= ch
     for name in SETUP_LIST:
         if name not in decls():
             continue
@@ -114,7 +117,10 @@ def get_setup_template(ch, srate, req):
             continue
         if not (t.samplerate_min_restriction <= srate <= t.samplerate_max_restriction):
             continue
-        m = [float(x) for x in val(t.quality_mapping)]
+        mp_ = t.rate_mapping if q_or_bitrate else t.quality_mapping
+        if mp_ in ("NULL", "0", 0, None):
+            continue
+        m = [float(x) for x in val(mp_)]
         mappings = t.mappings
         if req < m[0] or req > m[mappings]:
             continue
@@ -175,14 +181,28 @@ def book_arrays(name):
 
 
 # ---- the setup proper ------------------------------------------------------------
-def build(ch, rate, quality):
+def build(ch, rate, quality, managed=None):
+    """managed = (max_bitrate, nominal_bitrate, min_bitrate) selects vorbis_encode_setup_managed
+    (lib/vorbisenc.c:997-1047) instead of the VBR setup"""
     out = {}
-    # vorbis_encode_setup_vbr, lib/vorbisenc.c:952-975: float quality += .0000001 (double add, float store)
-    q = f32(float(f32(quality)) + .0000001)
-    if q >= 1.:
-        q = f32(.9999)
-    req = float(q)
-    t, base = get_setup_template(ch, rate, req)
+    if managed is None:
+        # vorbis_encode_setup_vbr, lib/vorbisenc.c:952-975: float quality += .0000001 (double add, float store)
+        q = f32(float(f32(quality)) + .0000001)
+        if q >= 1.:
+            q = f32(.9999)
+        req = float(q)
+        t, base = get_setup_template(ch, rate, req)
+    else:
+        max_bitrate, nominal_bitrate, min_bitrate = [int(x) for x in managed]
+        tnominal = float(nominal_bitrate)
+        if nominal_bitrate <= 0:                      # :1013-1027 (long arithmetic: doubles stored into a long)
+            if max_bitrate > 0:
+                nominal_bitrate = int((max_bitrate + min_bitrate) * .5) if min_bitrate > 0 else int(max_bitrate * .875)
+            elif min_bitrate > 0:
+                nominal_bitrate = min_bitrate
+            else:
+                raise ValueError("OV_EINVAL")
+        t, base = get_setup_template(ch, rate, float(nominal_bitrate), 1)
     is_ = int(base)
     ds = base - is_
 
@@ -201,6 +221,16 @@ def build(ch, rate, quality):
     hi["impulse_noisetune"] = 0.   # vorbis_info_init callocs codec_setup_info
     hi["managed"] = 0
     hi["coupling_p"] = 1
+    hi["bitrate_min"] = hi["bitrate_max"] = 0
+    hi["bitrate_av"] = 0.
+    if managed is not None:                           # :1035-1044
+        hi["managed"] = 1
+        hi["bitrate_min"] = min_bitrate
+        hi["bitrate_max"] = max_bitrate
+        hi["bitrate_av"] = int(tnominal)              # long bitrate_av
+        hi["bitrate_av_damp"] = 1.5
+        hi["bitrate_reservoir"] = nominal_bitrate * 2
+        hi["bitrate_reservoir_bias"] = .1
 
     # ---- vorbis_encode_setup_init, lib/vorbisenc.c:722-905
     i0 = 0 if hi["impulse_block_p"] else 1
@@ -306,15 +336,15 @@ def build(ch, rate, quality):
         mid = PACKETBLOBS // 2
         k0 = [f32lit(v) for v in pad(p0[2], PACKETBLOBS, 0.)]
         k1 = [f32lit(v) for v in pad(p1[2], PACKETBLOBS, 0.)]
-        kHz = f32(float(k0[mid]) * (1. - sds) + float(k1[mid]) * sds)
+        l0 = [f32lit(v) for v in pad(p0[3], PACKETBLOBS, 0.)]
+        l1 = [f32lit(v) for v in pad(p1[3], PACKETBLOBS, 0.)]
         for i in range(PACKETBLOBS):
+            src = i if hi["managed"] else mid         # managed: every blob its own thresholds (:270-283)
+            kHz = f32(float(k0[src]) * (1. - sds) + float(k1[src]) * sds)
             g["coupling_pointlimit"][0][i] = int(float(kHz) * 1000. / rate * blocksizes[0])
             g["coupling_pointlimit"][1][i] = int(float(kHz) * 1000. / rate * blocksizes[1])
             g["coupling_pkHz"][i] = int(kHz)
-        l0 = [f32lit(v) for v in pad(p0[3], PACKETBLOBS, 0.)]
-        l1 = [f32lit(v) for v in pad(p1[3], PACKETBLOBS, 0.)]
-        kHz = f32(float(l0[mid]) * (1. - sds) + float(l1[mid]) * sds)
-        for i in range(PACKETBLOBS):
+            kHz = f32(float(l0[src]) * (1. - sds) + float(l1[src]) * sds)
             g["sliding_lowpass"][0][i] = int(float(kHz) * 1000. / rate * blocksizes[0])
             g["sliding_lowpass"][1][i] = int(float(kHz) * 1000. / rate * blocksizes[1])
     else:
@@ -504,6 +534,8 @@ def build(ch, rate, quality):
                  "partitions": partitions, "partvals": partvals, "groupbook": groupbook,
                  "secondstages": pad(rsrc[6], 64), "booklist": pad(rsrc[7], 512),
                  "classmetric1": pad(rsrc[8], 64), "classmetric2": pad(rsrc[9], 64)}
+            if hi["managed"]:                        # :513-530
+                books_base, book_aux = books_base_m, book_aux_m
             bb = val(books_base)[0]
             bb = [pad(row if isinstance(row, list) else [row], 4) for row in bb]
             bb = bb + [[0, 0, 0, 0]] * (12 - len(bb))
@@ -528,7 +560,7 @@ def build(ch, rate, quality):
                 freq = nyq
             f["n"] = int(freq / nyq * blocksize)
             if limit_type == 1:
-                freq = g["coupling_pkHz"][PACKETBLOBS // 2] * 1000.
+                freq = g["coupling_pkHz"][PACKETBLOBS - 1 if hi["managed"] else PACKETBLOBS // 2] * 1000.
                 if freq > nyq:
                     freq = nyq
             elif limit_type == 2:
@@ -577,12 +609,18 @@ def build(ch, rate, quality):
     else:
         r = [float(x) for x in val(rm)]
         nominal = int((r[is_] * (1. - ds) + r[is_ + 1] * ds) * ch)
-    out["info/bitrates"] = np.array([0, nominal, 0], np.int64)
+    if hi["bitrate_av"] > 0:                          # :877-884
+        nominal = int(hi["bitrate_av"])
+    out["info/bitrates"] = np.array([hi["bitrate_max"], nominal, hi["bitrate_min"]], np.int64)
+    if hi["managed"]:                                 # bitrate_manager_info, :890-901
+        out["bi/rates"] = np.array([hi["bitrate_av"], hi["bitrate_min"], hi["bitrate_max"],
+                                    hi["bitrate_reservoir"]], np.int64)
+        out["bi/floats"] = np.array([hi["bitrate_reservoir_bias"], hi["bitrate_av_damp"]], np.float64)
     out["info/template"] = np.frombuffer(t.name.encode(), dtype=np.uint8)
     out["info/blocksizes"] = np.array(blocksizes, I32)
     out["info/counts"] = np.array([nmodes, nmodes, len(floors), nres, len(books.names), npsy], I32)
     out["info/block_lowpassr"] = np.array(block_lowpassr, I32)
-    out["info/managed"] = np.array([0], I32)
+    out["info/managed"] = np.array([hi["managed"]], I32)
     out["hi/pre_amplitude"] = np.array([hi["pre_amplitude"]], F32)
     out["hi/lowpass_kHz"] = np.array([hi["lowpass_kHz"]], np.float64)
     for i, m in enumerate(modes):
@@ -647,15 +685,26 @@ def build(ch, rate, quality):
     return out
 
 
-def pack_name(ch, rate, quality):
+def pack_name(ch, rate, quality, managed=None):
+    if managed is not None:
+        mx, nom, mn = managed
+        return f"mode_{ch}ch_{rate}_b{nom}" + (f"_max{mx}" if mx > 0 else "") + (f"_min{mn}" if mn > 0 else "") + ".vpk"
     return f"mode_{ch}ch_{rate}_q{quality:g}.vpk"
 
 
 if __name__ == "__main__":
-    ch, rate, quality = int(sys.argv[1]), int(sys.argv[2]), float(sys.argv[3])
-    arrays = build(ch, rate, quality)
+    # make_modepack.py ch rate quality            (vorbis_encode_init_vbr)
+    # make_modepack.py ch rate b<nominal> [max [min]]   (vorbis_encode_init: managed bitrate, bits/s)
+    ch, rate = int(sys.argv[1]), int(sys.argv[2])
+    managed, quality = None, None
+    if sys.argv[3].startswith("b"):
+        managed = (int(sys.argv[4]) if len(sys.argv) > 4 else -1, int(sys.argv[3][1:]),
+                   int(sys.argv[5]) if len(sys.argv) > 5 else -1)
+    else:
+        quality = float(sys.argv[3])
+    arrays = build(ch, rate, quality, managed)
     os.makedirs(DATA, exist_ok=True)
-    path = os.path.join(DATA, pack_name(ch, rate, quality))
+    path = os.path.join(DATA, pack_name(ch, rate, quality, managed))
     write_vpk(path, arrays)
     c = arrays["info/counts"]
     print(f"{path}: template={bytes(arrays['info/template']).decode()} base={arrays['info/base_setting'][0]:.7f} "

@@ -12,20 +12,27 @@ from ._lib import lib, check
 _DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
 
 
-def mode_pack_path(channels, rate, quality):
-    return os.path.join(_DATA, f"mode_{channels}ch_{rate}_q{quality:g}.vpk")
+def mode_pack_path(channels, rate, quality=None, bitrate=None):
+    """bitrate: nominal bits/s or (max, nominal, min) as given to vorbis_encode_init (-1 = unset)"""
+    if bitrate is None:
+        return os.path.join(_DATA, f"mode_{channels}ch_{rate}_q{quality:g}.vpk")
+    mx, nom, mn = bitrate if isinstance(bitrate, (tuple, list)) else (-1, bitrate, -1)
+    name = f"mode_{channels}ch_{rate}_b{nom}" + (f"_max{mx}" if mx > 0 else "") + (f"_min{mn}" if mn > 0 else "")
+    return os.path.join(_DATA, name + ".vpk")
 
 
 class Setup:
     """codec_setup_info + looks for one (channels, rate, quality) class (vorbis_encode_init_vbr +
-    vorbis_analysis_init in the reference), loaded from the shipped mode pack."""
+    vorbis_analysis_init in the reference) or, with bitrate=, one managed-bitrate class
+    (vorbis_encode_init), loaded from the shipped mode pack."""
 
-    def __init__(self, channels, rate, quality):
-        self.channels, self.rate, self.quality = channels, rate, quality
+    def __init__(self, channels, rate, quality=None, bitrate=None):
+        self.channels, self.rate, self.quality, self.bitrate = channels, rate, quality, bitrate
         self._h = C.c_void_p()
-        path = mode_pack_path(channels, rate, quality)
+        path = mode_pack_path(channels, rate, quality, bitrate)
         if not os.path.exists(path):
-            raise FileNotFoundError(f"no mode pack for {channels} ch / {rate} Hz / q{quality:g}: {path} "
+            raise FileNotFoundError(f"no mode pack for {channels} ch / {rate} Hz / "
+                                    f"{'q%g' % quality if bitrate is None else 'bitrate %s' % (bitrate,)}: {path} "
                                     "(generate one with tools/make_modepack.py)")
         check(lib.vbm_setup_create(C.byref(self._h), os.path.join(_DATA, "common.vpk").encode(), path.encode()),
               "vbm_setup_create")
