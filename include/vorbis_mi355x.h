@@ -165,6 +165,16 @@ int vbm_analysis_round(vbm_encoder *enc, const int *counts, const int *stream_id
  * "poste" "packet_bytes".  d_out may be NULL to query rows/kind ('f' float32, 'i' int32). */
 int vbm_encoder_fetch(vbm_encoder *enc, const char *name, void *d_out, long *rows, char *kind, void *stream);
 
+/* Managed bitrate (setups made by vorbis_encode_init: reference lib/vorbisenc.c:997-1070).  With such a
+ * setup vbm_analysis_batch / _batch2 / _round and the front end do per block what vorbis_analysis(vb, NULL)
+ * + vorbis_bitrate_addblock + vorbis_bitrate_flushpacket do (lib/analysis.c:30-62, lib/bitrate.c:73-252):
+ * all PACKETBLOBS (15) packets of the block are produced (lib/mapping0.c:1097-1181, loop :1204), the
+ * stream's reservoirs pick one, and that packet — truncated to the ceiling or zero-padded to the floor when
+ * max / min rates are set — is the one handed out.  Nothing in the call sequence changes.  For parity tests:
+ * packetblob k of the LAST batch as produced, before the choice (d_packets [nsb][max_packet_bytes],
+ * d_packet_bytes [nsb]; either may be NULL), and the vector "choice" of vbm_encoder_fetch. */
+int vbm_encoder_fetch_blob(vbm_encoder *enc, int k, uint8_t *d_packets, int *d_packet_bytes, void *stream);
+
 /* Sub-batches.  The transforms run on the whole batch; the stages after them run as `n` slices of
  * the batch (multiples of 64 stream-blocks), each on an internal HIP stream forked from and joined
  * back to the caller's stream with events, so that the serial few-wavefront kernels of one slice

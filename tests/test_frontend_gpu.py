@@ -86,12 +86,14 @@ def test_frontend_reproduces_reference_packet_dump(oracle, cuda, ch, rate, q, se
     assert got[0][-1][0][4] == 1 and all(m[4] == 0 for m, _ in got[0][:-1])      # e_o_s on the last packet only
 
 
-def frontend_vs_oracle(oracle, cuda, ch, rate, q, NS, seconds, need_modes=(0, 1, 2, 3), max_rounds=None):
+def frontend_vs_oracle(oracle, cuda, ch, rate, q, NS, seconds, need_modes=(0, 1, 2, 3), max_rounds=None, bitrate=None,
+                       sigs=None):
     import vorbis_aotuv_lancer_amd as v
     nsamp = int(seconds * rate) // 1024 * 1024
-    sigs = [synth_signal(ch, rate, nsamp, seed=500 + s, level=1.0 if s % 3 else 0.05) for s in range(NS)]
+    if sigs is None:
+        sigs = [synth_signal(ch, rate, nsamp, seed=500 + s, level=1.0 if s % 3 else 0.05) for s in range(NS)]
     # oracle: same write pattern (1024 at a time, drain after every write, then end of stream)
-    osetup = orc.Setup(oracle, ch, rate, q)
+    osetup = orc.Setup(oracle, ch, rate, q, bitrate=bitrate)
     want = []
     for s in range(NS):
         st = orc.Stream(osetup)
@@ -105,7 +107,7 @@ def frontend_vs_oracle(oracle, cuda, ch, rate, q, NS, seconds, need_modes=(0, 1,
         st.close()
         want.append([((b["lW"], b["W"], b["nW"], b["block_mode"], b["eos"], b["granulepos"], b["sequence"]), b["packet"])
                      for b in seq])
-    enc = v.Encoder(v.Setup(ch, rate, q), NS)
+    enc = v.Encoder(v.Setup(ch, rate, q, bitrate=bitrate), NS)
     fe = v.FrontEnd(enc)
     got = [[] for _ in range(NS)]
     allp = torch.from_numpy(np.stack(sigs)).to(cuda)

@@ -51,6 +51,7 @@ SIGNATURES = {
                                      C.c_void_p]),
     "vbm_encoder_fetch": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_char),
                                     C.c_void_p]),
+    "vbm_encoder_fetch_blob": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vbm_encoder_profile_begin": (C.c_int, [C.c_void_p, C.c_int]),
     "vbm_encoder_profile_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "vbm_encoder_set_sub_batches": (C.c_int, [C.c_void_p, C.c_int]),

@@ -22,6 +22,9 @@ struct vbm_stream_state {           // per-encoder, S streams (reference lib/cod
     float *g_ampmax;                // [S]         psy_g_look->ampmax
     float *vbi_ampmax;              // [S]         vorbis_block_internal.ampmax of the stream's block
     int *lW_block_mode, *lW_no, *impadnum;  // [S]
+    // bitrate_manager_state (lib/bitrate.h:25-39) of managed-bitrate setups
+    long long *bm_avg_reservoir, *bm_minmax_reservoir;   // [S]
+    double *bm_avgfloat;                                 // [S]
 };
 
 struct vbm_batch {
@@ -81,6 +84,13 @@ struct vbm_batch {
     int *packet_bytes;              // [Ls]
     int *packet_bits;               // [Ls]  write position while the packet is assembled
     int max_packet_bytes;           // multiple of 4
+    // managed bitrate (lib/mapping0.c:1097-1181, :1204): the back half runs once per packetblob
+    int blobno;                     // blob the floor encode / couple / pack kernels work on (PACKETBLOBS/2 for VBR)
+    int *postT_blob;                // [PACKETBLOBS][VIF_POSIT+2][L] in the tile slab: fits of blobs 0, 7, 14 + the interpolated ones
+    int *post_valid_blob;           // [PACKETBLOBS][L]
+    uint8_t *packetT_blob;          // [PACKETBLOBS] packet tiles, each laid out like packetT
+    int *packet_bytes_blob;         // [PACKETBLOBS][Ls]
+    int *choice;                    // [Ls] bm->choice of the block
     int pack_submaps;               // residue submaps of this block type and their partition counts (host copy)
     int pack_partvals[16];
 };

@@ -115,6 +115,22 @@ extern "C" void vbm_encoder_destroy(vbm_encoder *e)
     delete e;
 }
 
+// vorbis_bitrate_init (reference lib/bitrate.c:28-56): reservoirs at the desired fill, floater in the middle
+static int bitrate_state_init(vbm_encoder *e, vbm_stream_state &st)
+{
+    const vbm_setup *s = e->hs;
+    const long long fill = s->managed ? (long long)((double)s->bi_reservoir_bits * s->bi_reservoir_bias) : 0;
+    std::vector<long long> r(e->S, fill);
+    std::vector<double> f(e->S, (double)(VBM_PACKETBLOBS / 2));
+    if (hipMemcpy(st.bm_avg_reservoir, r.data(), e->S * sizeof(long long), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(st.bm_minmax_reservoir, r.data(), e->S * sizeof(long long), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(st.bm_avgfloat, f.data(), e->S * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+        g_vbm_err = "hipMemcpy(bitrate manager state) failed";
+        return VBM_EHIP;
+    }
+    return VBM_OK;
+}
+
 extern "C" int vbm_encoder_create(vbm_encoder **out, vbm_setup_handle *setup, int nstreams, int max_batch)
 {
     if (!out || !setup || nstreams <= 0 || max_batch <= 0) return VBM_EINVAL;
@@ -173,6 +189,11 @@ extern "C" int vbm_encoder_create(vbm_encoder **out, vbm_setup_handle *setup, in
     A(b.st.lW_block_mode, int, (size_t)nstreams);
     A(b.st.lW_no, int, (size_t)nstreams);
     A(b.st.impadnum, int, (size_t)nstreams);
+    A(b.st.bm_avg_reservoir, long long, (size_t)nstreams);
+    A(b.st.bm_minmax_reservoir, long long, (size_t)nstreams);
+    A(b.st.bm_avgfloat, double, (size_t)nstreams);
+    rc = bitrate_state_init(e, b.st);
+    if (rc) { vbm_encoder_destroy(e); return rc; }
     {
         std::vector<float> init(nstreams, -9999.f);
         (void)hipMemcpy(b.st.g_ampmax, init.data(), nstreams * sizeof(float), hipMemcpyHostToDevice);
@@ -202,7 +223,7 @@ extern "C" int vbm_encoder_create(vbm_encoder **out, vbm_setup_handle *setup, in
         const size_t o_mdct = take(nmax), o_logfft = take(nmax), o_logmdct = take(nmax), o_noise = take(nmax),
                      o_tone = take(nmax), o_logmask = take(nmax), o_epeak = take(nmax), o_work = take(nmax),
                      o_npeak = take(nmax / 8 + 1), o_sum = take((size_t)5 * nmax), o_seed = take(e->max_oct),
-                     o_amp = take(e->max_oct), o_pos = take(e->max_oct), o_post = take(VBM_VIF_POSIT + 2),
+                     o_amp = take(e->max_oct), o_pos = take(e->max_oct), o_post = take((size_t)(VBM_VIF_POSIT + 2) * VBM_PACKETBLOBS),
                      o_fout = take(VBM_VIF_POSIT + 2), o_iwork = take(nmax), o_ntfix = take(512);
         b.slab_words = rows * 64;
         float *slab;
@@ -211,7 +232,9 @@ extern "C" int vbm_encoder_create(vbm_encoder **out, vbm_setup_handle *setup, in
         b.noiseT = slab + o_noise; b.toneT = slab + o_tone; b.logmaskT = slab + o_logmask;
         b.epeakT = slab + o_epeak; b.workT = slab + o_work; b.npeakT = slab + o_npeak; b.sumT = slab + o_sum;
         b.seedT = slab + o_seed; b.ampstackT = slab + o_amp; b.posstackT = (int *)(slab + o_pos);
-        b.postT = (int *)(slab + o_post); b.floor_outT = (int *)(slab + o_fout); b.iworkT = (int *)(slab + o_iwork);
+        b.postT_blob = (int *)(slab + o_post);
+        b.postT = b.postT_blob + (size_t)(VBM_PACKETBLOBS / 2) * (VBM_VIF_POSIT + 2) * 64;
+        b.floor_outT = (int *)(slab + o_fout); b.iworkT = (int *)(slab + o_iwork);
         b.ntfixT = slab + o_ntfix;
 
         size_t srows = 0;
@@ -239,10 +262,16 @@ extern "C" int vbm_encoder_create(vbm_encoder **out, vbm_setup_handle *setup, in
     }
     A(b.poste, float, L);
     A(b.global_ampmax, float, Ls);
-    A(b.post_valid, int, L);
+    A(b.post_valid_blob, int, L * VBM_PACKETBLOBS);
+    b.post_valid = b.post_valid_blob + (size_t)(VBM_PACKETBLOBS / 2) * L;
     A(b.nonzero, int, L);
     A(b.packetT, uint8_t, Ls * (size_t)e->max_packet_bytes);   // [sb>>6][max_packet_bytes][64]
     A(b.packet_bytes, int, Ls);
+    if (s->managed) {   // one packet buffer per packetblob (lib/mapping0.c:1204)
+        A(b.packetT_blob, uint8_t, Ls * (size_t)e->max_packet_bytes * VBM_PACKETBLOBS);
+        A(b.packet_bytes_blob, int, Ls * VBM_PACKETBLOBS);
+        A(b.choice, int, Ls);
+    }
     A(b.packet_bits, int, Ls);
     b.stream_id = e->d_stream_id[w];
     b.wflags = e->d_wflags[w];
@@ -327,13 +356,15 @@ extern "C" int vbm_encoder_reset(vbm_encoder *e)
     std::vector<float> init(e->S, -9999.f);
     (void)hipMemcpy(st.g_ampmax, init.data(), e->S * sizeof(float), hipMemcpyHostToDevice);
     (void)hipMemcpy(st.vbi_ampmax, init.data(), e->S * sizeof(float), hipMemcpyHostToDevice);
-    return VBM_OK;
+    return bitrate_state_init(e, st);
 }
 
 // the listed streams start over (a new stream in a used slot); d_ids: device copy of the ids
 int vbm_encoder_reset_streams_dev(vbm_encoder *e, const int *d_ids, int n, hipStream_t q)
 {
-    return vbm_launch_reset_streams(&e->bw[0].st, d_ids, n, q) ? VBM_EHIP : VBM_OK;
+    const vbm_setup *s = e->hs;
+    const long long fill = s->managed ? (long long)((double)s->bi_reservoir_bits * s->bi_reservoir_bias) : 0;
+    return vbm_launch_reset_streams(&e->bw[0].st, d_ids, n, fill, q) ? VBM_EHIP : VBM_OK;
 }
 
 static void configure(vbm_encoder *e, vbm_batch &b, int block_mode, int nsb, const float *d_pcm, int w)
@@ -349,6 +380,7 @@ static void configure(vbm_encoder *e, vbm_batch &b, int block_mode, int nsb, con
     b.L = e->L;      // fixed leading dimensions: buffers were sized for `cap`
     b.Ls = e->Ls;
     b.pcm = d_pcm;
+    b.blobno = VBM_PACKETBLOBS / 2;
     {
         // partition slicing of couple/quantise (quant_kernels.hip): allowed when no channel takes part
         // in two coupling steps; lowpass rounding as lib/mapping0.c:778-781
@@ -395,16 +427,50 @@ static vbm_batch slice_of(const vbm_batch &f, int sb0, int nsb, uint8_t *d_packe
     v.stream_id += sb0; v.wflags += sb0;
     v.pcm += cb0 * f.N; v.mdct_bm += cb0 * f.n; v.logfft_bm += cb0 * f.n; v.qf_bm += cb0 * f.n;
     v.local_ampmax += cb0; v.wflags_cb += cb0; v.poste += cb0; v.post_valid += cb0; v.nonzero += cb0;
+    v.post_valid_blob += cb0;
     v.global_ampmax += sb0; v.packet_bytes += sb0; v.packet_bits += sb0;
+    if (v.packet_bytes_blob) { v.packet_bytes_blob += sb0; v.choice += sb0; v.packetT_blob += stl * 64 * (size_t)f.max_packet_bytes; }
     const size_t co = ct * f.slab_words;
     v.mdctT += co; v.logfftT += co; v.logmdctT += co; v.noiseT += co; v.toneT += co; v.logmaskT += co;
     v.epeakT += co; v.workT += co; v.npeakT += co; v.sumT += co; v.seedT += co; v.ampstackT += co;
-    v.posstackT += co; v.postT += co; v.floor_outT += co; v.iworkT += co; v.ntfixT += co;
+    v.posstackT += co; v.postT += co; v.postT_blob += co; v.floor_outT += co; v.iworkT += co; v.ntfixT += co;
     const size_t so = stl * f.sb_slab_words;
     v.partwordT += so; v.workvqT += so; v.m6defT += so; v.vqlenT += so; v.vqoffT += so;
     v.vqcodeT += stl * f.vq_slab_words;
     v.packetT += stl * 64 * (size_t)f.max_packet_bytes;
     return v;
+}
+
+// Managed bitrate (reference lib/mapping0.c:1044-1181): _vp_offset_and_mix + floor1_fit three times
+// (offset_select 1, 2, 0 -> blobs PACKETBLOBS/2, PACKETBLOBS-1, 0), the interpolated fits between, and
+// the block-state update the reference applies once per packetblob.
+static int managed_front(const vbm_batch &v, hipStream_t q)
+{
+    static const int sel[3] = {1, 2, 0}, slot[3] = {VBM_PACKETBLOBS / 2, VBM_PACKETBLOBS - 1, 0};
+    for (int t = 0; t < 3; t++) {
+        vbm_batch f = v;
+        f.postT = v.postT_blob + (size_t)slot[t] * (VBM_VIF_POSIT + 2) * 64;
+        f.post_valid = v.post_valid_blob + (size_t)slot[t] * v.L;
+        if (vbm_launch_mix_managed(&f, sel[t], q) || vbm_launch_floor_fit(&f, q)) return -2;
+    }
+    if (vbm_launch_block_state_managed(&v, q) || vbm_launch_floor_interp(&v, q)) return -2;
+    return 0;
+}
+
+// loop C once per packetblob (lib/mapping0.c:1204-1313), then vorbis_bitrate_addblock / _flushpacket
+// (lib/bitrate.c:98-252): choice, final lengths, the chosen packets
+static int managed_back(const vbm_batch &v, uint8_t *d_packets, hipStream_t q)
+{
+    for (int k = 0; k < VBM_PACKETBLOBS; k++) {
+        vbm_batch f = v;
+        f.blobno = k;
+        f.postT = v.postT_blob + (size_t)k * (VBM_VIF_POSIT + 2) * 64;
+        f.post_valid = v.post_valid_blob + (size_t)k * v.L;
+        f.packetT = v.packetT_blob + (size_t)k * v.Ls * v.max_packet_bytes;
+        f.packet_bytes = v.packet_bytes_blob + (size_t)k * v.Ls;
+        if (vbm_launch_floor_encode(&f, q) || vbm_launch_couple_quantize(&f, q) || vbm_launch_pack(&f, q)) return -2;
+    }
+    return vbm_launch_bitrate_choose(&v, d_packets, q);
 }
 
 extern "C" int vbm_analysis_batch(vbm_encoder *e, int block_mode, int nsb, const int *stream_ids,
@@ -526,19 +592,24 @@ extern "C" int vbm_analysis_batch2(vbm_encoder *e, int block_mode, int nsb, cons
             STAGE(4, q, RUN(vbm_launch_noisemask(&v, q)));
             STAGE(5, q, RUN(vbm_launch_tonemask(&v, q)));
         }
-        STAGE(6, q, { RUN(vbm_launch_mix(&v, q)); RUN(vbm_launch_block_state(&v, q)); });
+        if (s->managed) STAGE(6, q, RUN(managed_front(v, q)));
+        else STAGE(6, q, { RUN(vbm_launch_mix(&v, q)); RUN(vbm_launch_block_state(&v, q)); });
         if (two) {   // hand over to the back stream
             if ((err = hipEventRecord(e->ev_front[w], q)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
             if ((err = hipStreamWaitEvent(sback, e->ev_front[w], 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
             q = sback;
         }
+        if (s->managed) {
+            STAGE(10, q, RUN(managed_back(v, d_packets ? d_packets + (size_t)sb0 * e->max_packet_bytes : nullptr, q)));
+        } else {
         STAGE(7, q, RUN(vbm_launch_floor_fit(&v, q)));
         // loop C: floor encode, couple/quantise, residue + packet assembly
         STAGE(8, q, RUN(vbm_launch_floor_encode(&v, q)));
         STAGE(9, q, RUN(vbm_launch_couple_quantize(&v, q)));
         STAGE(10, q, RUN(vbm_launch_pack(&v, q)));
+        }
         STAGE(11, q, {
-            if (d_packets)   // word-major tiles -> [nsb][max_packet_bytes] bytes (little-endian words)
+            if (d_packets && !s->managed)   // word-major tiles -> [nsb][max_packet_bytes] bytes (little-endian words)
                 RUN(vbm_launch_untranspose_i32((const int *)v.packetT,
                                                (int *)(d_packets + (size_t)sb0 * e->max_packet_bytes),
                                                e->max_packet_bytes / 4, (size_t)(e->max_packet_bytes / 4) * 64,
@@ -660,13 +731,18 @@ extern "C" int vbm_analysis_round(vbm_encoder *e, const int *counts, const int *
         RUN(vbm_launch_prologue(&v, q));
         RUN(vbm_launch_noisemask(&v, q));
         RUN(vbm_launch_tonemask(&v, q));
+        if (s->managed) {
+            RUN(managed_front(v, q));
+            RUN(managed_back(v, d_packets ? d_packets + (size_t)off[m] * e->max_packet_bytes : nullptr, q));
+        } else {
         RUN(vbm_launch_mix(&v, q));
         RUN(vbm_launch_block_state(&v, q));
         RUN(vbm_launch_floor_fit(&v, q));
         RUN(vbm_launch_floor_encode(&v, q));
         RUN(vbm_launch_couple_quantize(&v, q));
         RUN(vbm_launch_pack(&v, q));
-        if (d_packets)
+        }
+        if (d_packets && !s->managed)
             RUN(vbm_launch_untranspose_i32((const int *)v.packetT, (int *)(d_packets + (size_t)off[m] * e->max_packet_bytes),
                                            e->max_packet_bytes / 4, (size_t)(e->max_packet_bytes / 4) * 64, v.nsb, q));
         if (d_packet_bytes &&
@@ -722,6 +798,27 @@ extern "C" int vbm_encoder_stage_count(void) { return kNumStages; }
 extern "C" const char *vbm_encoder_stage_name(int k) { return (k >= 0 && k < kNumStages) ? kStageNames[k] : ""; }
 
 // Stage intermediates of the LAST batch, converted to block-major rows, for parity tests.
+// managed bitrate: packetblob k of the last batch as it was before the bitrate manager chose
+// (packets [nsb][max_packet_bytes], lengths [nsb])
+extern "C" int vbm_encoder_fetch_blob(vbm_encoder *e, int k, uint8_t *d_packets, int *d_packet_bytes, void *stream)
+{
+    if (!e || e->last_nsb <= 0 || k < 0 || k >= VBM_PACKETBLOBS) return VBM_EINVAL;
+    if (!e->hs->managed) { g_vbm_err = "not a managed-bitrate setup"; return VBM_EINVAL; }
+    vbm_batch b;
+    configure(e, b, e->last_mode, e->last_nsb, nullptr, e->cur);
+    hipStream_t st = (hipStream_t)stream;
+    if (d_packets &&
+        vbm_launch_untranspose_i32((const int *)(b.packetT_blob + (size_t)k * b.Ls * b.max_packet_bytes), (int *)d_packets,
+                                   e->max_packet_bytes / 4, (size_t)(e->max_packet_bytes / 4) * 64, b.nsb, st))
+        return VBM_EHIP;
+    if (d_packet_bytes) {
+        hipError_t err = hipMemcpyAsync(d_packet_bytes, b.packet_bytes_blob + (size_t)k * b.Ls, (size_t)b.nsb * sizeof(int),
+                                        hipMemcpyDeviceToDevice, st);
+        if (err != hipSuccess) return vbm_set_hip_error(err, "hipMemcpyAsync(fetch_blob)");
+    }
+    return VBM_OK;
+}
+
 extern "C" int vbm_encoder_fetch(vbm_encoder *e, const char *name, void *d_out, long *rows_out, char *kind,
                                  void *stream)
 {
@@ -766,9 +863,10 @@ extern "C" int vbm_encoder_fetch(vbm_encoder *e, const char *name, void *d_out, 
         {"local_ampmax", b.local_ampmax, 'f', b.ncb}, {"global_ampmax", b.global_ampmax, 'f', b.nsb},
         {"post_valid", b.post_valid, 'i', b.ncb},     {"nonzero", b.nonzero, 'i', b.ncb},
         {"poste", b.poste, 'f', b.ncb},               {"packet_bytes", b.packet_bytes, 'i', b.nsb},
+        {"choice", b.choice, 'i', b.choice ? b.nsb : 0},            // managed bitrate: bm->choice per stream-block
     };
     for (const Vec &t : vecs) {
-        if (strcmp(t.name, name)) continue;
+        if (strcmp(t.name, name) || !t.ptr) continue;
         if (rows_out) *rows_out = 1;
         if (kind) *kind = t.kind;
         if (!d_out) return VBM_OK;

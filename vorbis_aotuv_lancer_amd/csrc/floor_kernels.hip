@@ -386,6 +386,43 @@ __global__ void k_floor_fit(vbm_batch b, int lpw)
     b.post_valid[lane] = 1;
 }
 
+// floor1_interpolate_fit for the blobs between the three fitted ones (lib/mapping0.c:1169-1181,
+// lib/floor1.c:752-771): 16.16 fixed-point blend; a blob has posts only if both of its ends do, and none
+// of the extra blobs has when the first fit (blob PACKETBLOBS/2) found nothing
+__global__ void k_floor_interp(vbm_batch b)
+{
+    const int lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= b.ncb) return;
+    const size_t tb = (size_t)(lane >> 6) * b.slab_words + (lane & 63);
+    const vbm_setup *s = b.setup;
+    const int c = lane % b.ch;
+    const vbm_map *map = &s->map[b.W];
+    const int posts = s->floor[map->floorsubmap[map->chmuxlist[c]]].posts;
+    const int PR = (VBM_VIF_POSIT + 2) * 64, MID = VBM_PACKETBLOBS / 2, LAST = VBM_PACKETBLOBS - 1;
+    int *valid = b.post_valid_blob + lane;
+    const size_t L = (size_t)b.L;
+    const int vm = valid[(size_t)MID * L];
+    const int v0 = vm && valid[0], v14 = vm && valid[(size_t)LAST * L];
+    valid[0] = v0;
+    valid[(size_t)LAST * L] = v14;
+    for (int k = 1; k < LAST; k++) {
+        if (k == MID) continue;
+        const int lo = k < MID;
+        const int ok = lo ? v0 : v14;
+        valid[(size_t)k * L] = ok;
+        if (!ok) continue;
+        const int *A = b.postT_blob + (size_t)(lo ? 0 : MID) * PR, *B = b.postT_blob + (size_t)(lo ? MID : LAST) * PR;
+        int *out = b.postT_blob + (size_t)k * PR;
+        const int del = (lo ? k : k - MID) * 65536 / MID;
+        for (int i = 0; i < posts; i++) {
+            const int a = T(A, i), bb = T(B, i);
+            int o = ((65536 - del) * (a & 0x7fff) + del * (bb & 0x7fff) + 32768) >> 16;
+            if ((a & 0x8000) && (bb & 0x8000)) o |= 0x8000;
+            T(out, i) = o;
+        }
+    }
+}
+
 __global__ void k_floor_encode(vbm_batch b)
 {
     const int lane = blockIdx.x * blockDim.x + threadIdx.x;
@@ -517,6 +554,11 @@ extern "C" int vbm_launch_floor_fit(const vbm_batch *b, hipStream_t st)
     hipLaunchKernelGGL(k_floor_prep, dim3((unsigned)((b->ncb + 63) / 64), (unsigned)((b->n + 63) / 64)), dim3(256), 0,
                        st, *b);
     hipLaunchKernelGGL(k_floor_fit, dim3((unsigned)((b->ncb + lpw - 1) / lpw)), dim3(64), 0, st, *b, lpw);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+extern "C" int vbm_launch_floor_interp(const vbm_batch *b, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_floor_interp, grid_for(b->ncb), dim3(64), 0, st, *b);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 extern "C" int vbm_launch_floor_encode(const vbm_batch *b, hipStream_t st)

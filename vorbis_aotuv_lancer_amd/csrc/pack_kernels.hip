@@ -282,7 +282,9 @@ __global__ void k_pack_head(vbm_batch b)
 }
 
 // classification of partitions [i0, i1) of one stream-block (res*_class) + the res2 interleave
-__global__ void k_block_state(vbm_batch b)
+// `reps`: the update sits inside the reference's loop over the packetblobs (lib/mapping0.c:1204, :1296-1304),
+// so a managed-bitrate stream applies it PACKETBLOBS times per block
+__global__ void k_block_state(vbm_batch b, int reps)
 {
     const int sb = blockIdx.x * blockDim.x + threadIdx.x;
     if (sb >= b.nsb) return;
@@ -291,14 +293,175 @@ __global__ void k_block_state(vbm_batch b)
     int impadnum = b.st.impadnum[sid];
     int lWbm = b.st.lW_block_mode[sid];
     int lW_no = b.st.lW_no[sid];
-    if (block_mode >= 2) impadnum = 0;
-    if ((!lWbm) && (block_mode == 1)) impadnum = 1;
-    else if (impadnum && impadnum < 8) impadnum++;
-    if (lWbm == block_mode) lW_no++;
-    else lW_no = 1;
+    for (int r = 0; r < reps; r++) {
+        if (block_mode >= 2) impadnum = 0;
+        if ((!lWbm) && (block_mode == 1)) impadnum = 1;
+        else if (impadnum && impadnum < 8) impadnum++;
+        if (lWbm == block_mode) lW_no++;
+        else lW_no = 1;
+        lWbm = block_mode;
+    }
     b.st.impadnum[sid] = impadnum;
     b.st.lW_no[sid] = lW_no;
     b.st.lW_block_mode[sid] = block_mode;
+}
+
+// vorbis_bitrate_addblock, managed branch (lib/bitrate.c:98-226), one lane per stream-block: choose one of the
+// PACKETBLOBS packets from the stream's reservoirs, settle its final length (truncated to the ceiling or
+// zero-padded to the floor), update the reservoirs.  The chosen packet is gathered by k_blob_gather.
+__global__ void k_bitrate_choose(vbm_batch b)
+{
+    const int sb = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sb >= b.nsb) return;
+    const vbm_setup *s = b.setup;
+    const int sid = b.stream_id[sb];
+    const int *__restrict__ sizes = b.packet_bytes_blob + sb;      // blob k at [k * Ls]
+    const size_t Ls = (size_t)b.Ls;
+#define BYTES(k) ((long long)sizes[(size_t)(k) * Ls])
+    // vorbis_bitrate_init (lib/bitrate.c:28-56)
+    const long long ratesamples = s->rate;
+    const int halfsamples = s->blocksizes[0] >> 1;
+    const long long short_per_long = s->blocksizes[1] / s->blocksizes[0];
+    const long long avg_bitsper = (long long)rint(1. * (double)s->bi_avg_rate * halfsamples / (double)ratesamples);
+    const long long min_bitsper = (long long)rint(1. * (double)s->bi_min_rate * halfsamples / (double)ratesamples);
+    const long long max_bitsper = (long long)rint(1. * (double)s->bi_max_rate * halfsamples / (double)ratesamples);
+
+    long long avg_reservoir = b.st.bm_avg_reservoir[sid], minmax_reservoir = b.st.bm_minmax_reservoir[sid];
+    double avgfloat = b.st.bm_avgfloat[sid];
+
+    int choice = (int)rint(avgfloat);
+    long long this_bits = BYTES(choice) * 8;
+    const long long min_target_bits = (b.W ? min_bitsper * short_per_long : min_bitsper);
+    const long long max_target_bits = (b.W ? max_bitsper * short_per_long : max_bitsper);
+    const int samples = s->blocksizes[b.W] >> 1;
+    const long long desired_fill = (long long)((double)s->bi_reservoir_bits * s->bi_reservoir_bias);
+    long long final_bytes;
+
+    if (avg_bitsper > 0) {
+        double slew = 0.;
+        const long long avg_target_bits = (b.W ? avg_bitsper * short_per_long : avg_bitsper);
+        const double slewlimit = 15. / s->bi_slew_damp;
+        if (avg_reservoir + (this_bits - avg_target_bits) > desired_fill) {
+            while (choice > 0 && this_bits > avg_target_bits && avg_reservoir + (this_bits - avg_target_bits) > desired_fill) {
+                choice--;
+                this_bits = BYTES(choice) * 8;
+            }
+        } else if (avg_reservoir + (this_bits - avg_target_bits) < desired_fill) {
+            while (choice + 1 < VBM_PACKETBLOBS && this_bits < avg_target_bits &&
+                   avg_reservoir + (this_bits - avg_target_bits) < desired_fill) {
+                choice++;
+                this_bits = BYTES(choice) * 8;
+            }
+        }
+        slew = rint((double)choice - avgfloat) / samples * (double)s->rate;
+        if (slew < -slewlimit) slew = -slewlimit;
+        if (slew > slewlimit) slew = slewlimit;
+        avgfloat += slew / (double)s->rate * samples;
+        choice = (int)rint(avgfloat);
+        this_bits = BYTES(choice) * 8;
+    }
+
+    if (min_bitsper > 0) {
+        if (this_bits < min_target_bits) {
+            while (minmax_reservoir - (min_target_bits - this_bits) < 0) {
+                choice++;
+                if (choice >= VBM_PACKETBLOBS) break;
+                this_bits = BYTES(choice) * 8;
+            }
+        }
+    }
+    if (max_bitsper > 0) {
+        if (this_bits > max_target_bits) {
+            while (minmax_reservoir + (this_bits - max_target_bits) > s->bi_reservoir_bits) {
+                choice--;
+                if (choice < 0) break;
+                this_bits = BYTES(choice) * 8;
+            }
+        }
+    }
+
+    if (choice < 0) {
+        const long long maxsize = (max_target_bits + (s->bi_reservoir_bits - minmax_reservoir)) / 8;
+        choice = 0;
+        final_bytes = BYTES(choice);
+        if (final_bytes > maxsize) final_bytes = maxsize;          // oggpack_writetrunc(maxsize*8)
+        this_bits = final_bytes * 8;
+    } else {
+        long long minsize = (min_target_bits - minmax_reservoir + 7) / 8;
+        if (choice >= VBM_PACKETBLOBS) choice = VBM_PACKETBLOBS - 1;
+        final_bytes = BYTES(choice);
+        minsize -= final_bytes;
+        if (minsize > 0) final_bytes += minsize;                    // zero bytes appended
+        this_bits = final_bytes * 8;
+    }
+
+    if (min_bitsper > 0 || max_bitsper > 0) {
+        if (max_target_bits > 0 && this_bits > max_target_bits) {
+            minmax_reservoir += (this_bits - max_target_bits);
+        } else if (min_target_bits > 0 && this_bits < min_target_bits) {
+            minmax_reservoir += (this_bits - min_target_bits);
+        } else {
+            if (minmax_reservoir > desired_fill) {
+                if (max_target_bits > 0) {
+                    minmax_reservoir += (this_bits - max_target_bits);
+                    if (minmax_reservoir < desired_fill) minmax_reservoir = desired_fill;
+                } else {
+                    minmax_reservoir = desired_fill;
+                }
+            } else {
+                if (min_target_bits > 0) {
+                    minmax_reservoir += (this_bits - min_target_bits);
+                    if (minmax_reservoir > desired_fill) minmax_reservoir = desired_fill;
+                } else {
+                    minmax_reservoir = desired_fill;
+                }
+            }
+        }
+    }
+    if (avg_bitsper > 0) {
+        const long long avg_target_bits = (b.W ? avg_bitsper * short_per_long : avg_bitsper);
+        avg_reservoir += this_bits - avg_target_bits;
+    }
+#undef BYTES
+    b.st.bm_avg_reservoir[sid] = avg_reservoir;
+    b.st.bm_minmax_reservoir[sid] = minmax_reservoir;
+    b.st.bm_avgfloat[sid] = avgfloat;
+    b.choice[sb] = choice;
+    // a padded packet may not outgrow the buffer (the reference's packer would simply grow)
+    b.packet_bytes[sb] = final_bytes <= b.max_packet_bytes ? (int)final_bytes : -1;
+}
+
+// packet words of the chosen blob -> dst[sb][max_packet_bytes/4] (vorbis_bitrate_flushpacket, lib/bitrate.c:229-252);
+// bytes past the final length are zero (truncation), bytes past the blob's own length already are (padding)
+__global__ void k_blob_gather(vbm_batch b, uint32_t *__restrict__ dst)
+{
+    __shared__ uint32_t tile[64][65];
+    const int rows = b.max_packet_bytes / 4;
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const size_t blob_stride = (size_t)b.Ls * b.max_packet_bytes;   // bytes per blob
+    {
+        const int c = c0 + tx;
+        const bool live = c < b.nsb;
+        const int k = live ? b.choice[c] : 0;
+        const int len = live ? b.packet_bytes[c] : 0;
+        const uint32_t *src = (const uint32_t *)(b.packetT_blob + (size_t)k * blob_stride) + (size_t)(c >> 6) * rows * 64 + (c & 63);
+        for (int rr = ty; rr < 64; rr += 4) {
+            const int r = r0 + rr;
+            uint32_t w = 0;
+            if (live && r < rows && r * 4 < len) {
+                w = src[(size_t)r * 64];
+                const int keep = len - r * 4;                      // bytes of this word inside the packet
+                if (keep < 4) w &= (1u << (8 * keep)) - 1u;
+            }
+            tile[rr][tx] = w;
+        }
+    }
+    __syncthreads();
+    for (int cc = ty; cc < 64; cc += 4) {
+        const int c = c0 + cc, r = r0 + tx;
+        if (c < b.nsb && r < rows) dst[(size_t)c * rows + r] = tile[tx][cc];
+    }
 }
 
 __device__ __forceinline__ void res_classify(const vbm_batch &b, const res_view &v, const int sb, const size_t col0, const int i0, const int i1)
@@ -515,7 +678,24 @@ __global__ void k_res_emit(vbm_batch b, int sm, int nchunks)
 
 extern "C" int vbm_launch_block_state(const vbm_batch *b, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_block_state, dim3((unsigned)((b->nsb + 63) / 64)), dim3(64), 0, st, *b);
+    hipLaunchKernelGGL(k_block_state, dim3((unsigned)((b->nsb + 63) / 64)), dim3(64), 0, st, *b, 1);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+extern "C" int vbm_launch_block_state_managed(const vbm_batch *b, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_block_state, dim3((unsigned)((b->nsb + 63) / 64)), dim3(64), 0, st, *b, VBM_PACKETBLOBS);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+// after all PACKETBLOBS packets of the batch exist: choice + final lengths into b->choice / b->packet_bytes,
+// the chosen packets into d_packets [nsb][max_packet_bytes] (may be NULL)
+extern "C" int vbm_launch_bitrate_choose(const vbm_batch *b, uint8_t *d_packets, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_bitrate_choose, dim3((unsigned)((b->nsb + 63) / 64)), dim3(64), 0, st, *b);
+    if (d_packets) {
+        const int rows = b->max_packet_bytes / 4;
+        hipLaunchKernelGGL(k_blob_gather, dim3((unsigned)((b->nsb + 63) / 64), (unsigned)((rows + 63) / 64)), dim3(256), 0, st,
+                           *b, (uint32_t *)d_packets);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

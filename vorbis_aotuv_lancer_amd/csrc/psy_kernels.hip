@@ -10,8 +10,9 @@
 //                 ntfix (:3645-3768), compander, M2 post-echo, M8, M9
 //   k_tonemask    _vp_tonemask (lib/psy.c:4076-4142): seed_loop/seed_curve (:652-771),
 //                 max_seeds/seed_chase (:773-1085)
-//   k_mix         _vp_offset_and_mix with offset_select 1, VBR (lib/psy.c:4274-4502, set_m3p
-//                 :4148-4272), including the aoTuV carried buffers lastmdct / tempmdct
+//   k_mix         _vp_offset_and_mix (lib/psy.c:4274-4502, set_m3p :4148-4272): offset_select 1 for VBR,
+//                 1 / 2 / 0 with bit_managed for managed bitrate, including the aoTuV carried buffers
+//                 lastmdct / tempmdct
 // The order-bound float accumulations (the five prefix sums of bark_noise_hybridmp, the
 // partition sums of M8) stay serial per lane, exactly in source order; table-driven loop
 // bounds are identical in every lane, so the wave runs them in lockstep and table reads are
@@ -723,10 +724,14 @@ struct mod3 {
 // Bins are independent for every block type except impulse short blocks (M3 reads and rewrites
 // tempmdct across bins and updates npeak per partition in bin order), so the launch splits the
 // bin range into `nchunks` slices (blockIdx.y) for block modes 1..3 and uses one slice for mode 0.
+template <int SEL, bool MANAGED>
 __global__ void k_mix(vbm_batch b, int nchunks)
 {
     const int lane = blockIdx.x * blockDim.x + threadIdx.x;
     if (lane >= b.ncb) return;
+    // managed bitrate: the hi / lo rate passes run only for channels whose first fit exists (lib/mapping0.c:1097)
+    if (MANAGED && SEL != 1 && !b.post_valid_blob[(size_t)(VBM_PACKETBLOBS / 2) * b.L + lane]) return;
+    constexpr bool BUF = (!MANAGED || SEL == 2);   // mp->mdctbuf_flag of set_m3p when the rate is high (lib/psy.c:4165-4173)
     const size_t tb = TB(b, lane);
     const vbm_setup *s = b.setup;
     const vbm_psy *p = psy_of(b);
@@ -741,7 +746,7 @@ __global__ void k_mix(vbm_batch b, int nchunks)
 #define TEMP(i) tempmdct[(size_t)(i) * 64]
     const float *noise = b.noiseT, *tone = b.toneT;
     float *logmask = b.logmaskT, *mdct = b.mdctT, *logmdct = b.logmdctT, *npeak = b.npeakT;
-    const int offset_select = 1;
+    const int offset_select = SEL;
     const int block_mode = b.block_mode;
     const int nW_modenumber = (b.wflags[sb] >> 1) & 1;
     const int lW_block_mode = b.st.lW_block_mode[sid];
@@ -767,13 +772,15 @@ __global__ void k_mix(vbm_batch b, int nchunks)
     if (low_compand < 0 || (double)toneatt < 25.) low_compand = 0;
     else low_compand = (float)((double)low_compand * ((double)toneatt - 25.));
 
-    // set_m3p (lib/psy.c:4148-4272), VBR: bit_managed == 0
+    // set_m3p (lib/psy.c:4148-4272)
     if (!hsrate) {
         mp3.sw = 0;
         mp3.mdctbuf_flag = 0;
     } else {
-        mp3.mdctbuf_flag = 1;
-        if (block_mode) {
+        mp3.mdctbuf_flag = BUF ? 1 : 0;
+        if (MANAGED && SEL == 0) {   // high noise scene
+            mp3.sw = 0;
+        } else if (block_mode) {
             mp3.sw = 0;
         } else if (n == 128 || n == 256) {
             const int *bfn = (n == 128) ? s->freq_bfn128 : s->freq_bfn256;
@@ -792,17 +799,17 @@ __global__ void k_mix(vbm_batch b, int nchunks)
                         mp3.tone_rate = 0;
                         if ((lW_no * count) < 24) mp3.noise_center = lW_no * count;
                     }
-                    for (i = 0; i < n; i++) TEMP(i) -= 5;
+                    if (BUF) for (i = 0; i < n; i++) TEMP(i) -= 5;
                 } else {
                     mp3.noise_rate = (float)0.7;
                     mp3.noise_center = 0;
                     mp3.tone_rate = 8.f;
-                    for (i = 0; i < n; i++) TEMP(i) = LAST(i) - 5;
+                    if (BUF) for (i = 0; i < n; i++) TEMP(i) = LAST(i) - 5;
                 }
                 mp3.noise_rate_low = 0;
                 mp3.sw = 1;
                 if (impadnum) mp3.noise_rate = (float)((double)mp3.noise_rate * (impadnum * 0.125));
-                for (i = 0; i < n; i++) {
+                if (BUF) for (i = 0; i < n; i++) {
                     float cell = 75 / (float)bfn[i];
                     for (j = 1; j < bfn[i]; j++) {
                         float freqbuf = T(logmdct, i) - (cell * j);
@@ -821,17 +828,17 @@ __global__ void k_mix(vbm_batch b, int nchunks)
                         mp3.noise_center = 30;
                         mp3.tone_rate = 0;
                     }
-                    for (i = 0; i < n; i++) TEMP(i) -= 10;
+                    if (BUF) for (i = 0; i < n; i++) TEMP(i) -= 10;
                 } else {
                     mp3.noise_rate = (float)0.6;
                     mp3.noise_center = 12;
                     mp3.tone_rate = 8.f;
-                    for (i = 0; i < n; i++) TEMP(i) = LAST(i) - 10;
+                    if (BUF) for (i = 0; i < n; i++) TEMP(i) = LAST(i) - 10;
                 }
                 mp3.noise_rate_low = 0;
                 mp3.sw = 1;
                 if (impadnum) mp3.noise_rate = (float)((double)mp3.noise_rate * (impadnum * 0.0625));
-                for (i = 0; i < n; i++) {
+                if (BUF) for (i = 0; i < n; i++) {
                     float cell = 75 / (float)bfn[i];
                     for (j = 1; j < bfn[i]; j++) {
                         float freqbuf = T(logmdct, i) - (cell * j);
@@ -930,7 +937,7 @@ __global__ void k_mix(vbm_batch b, int nchunks)
             T(logmask, i) = tval;
 
         // M1 (offset_select == 1)
-        {
+        if (SEL == 1) {
             m1_coeffi = (float)-17.2;
             val = val - lm;
             if (val > m1_coeffi) {
@@ -1022,6 +1029,16 @@ extern "C" int vbm_launch_tonemask(const vbm_batch *b, hipStream_t st)
 extern "C" int vbm_launch_mix(const vbm_batch *b, hipStream_t st)
 {
     const int nchunks = (b->block_mode == 0) ? 1 : bin_chunks(b);
-    hipLaunchKernelGGL(k_mix, dim3((unsigned)((b->ncb + 63) / 64), (unsigned)nchunks), dim3(64), 0, st, *b, nchunks);
+    hipLaunchKernelGGL((k_mix<1, false>), dim3((unsigned)((b->ncb + 63) / 64), (unsigned)nchunks), dim3(64), 0, st, *b, nchunks);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+// managed bitrate: offset_select 1 (first fit), 2 (higher rate), 0 (lower rate), lib/mapping0.c:1044-1160
+extern "C" int vbm_launch_mix_managed(const vbm_batch *b, int offset_select, hipStream_t st)
+{
+    const int nchunks = (b->block_mode == 0) ? 1 : bin_chunks(b);
+    const dim3 grid((unsigned)((b->ncb + 63) / 64), (unsigned)nchunks);
+    if (offset_select == 1) hipLaunchKernelGGL((k_mix<1, true>), grid, dim3(64), 0, st, *b, nchunks);
+    else if (offset_select == 2) hipLaunchKernelGGL((k_mix<2, true>), grid, dim3(64), 0, st, *b, nchunks);
+    else hipLaunchKernelGGL((k_mix<0, true>), grid, dim3(64), 0, st, *b, nchunks);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -3,7 +3,7 @@
 //   k_couple_quantize   _vp_couple_quantize_normalize (reference lib/psy.c:4858-5142) with
 //                       flag_lossless :4584-4624, noise_normalize :4732-4854 (ssort :4709),
 //                       lossless_coupling(f) :4626-4658, min_indemnity_dipole_hypot :4660-4673,
-//                       VBR blob PACKETBLOBS/2.
+//                       blob b.blobno (PACKETBLOBS/2 for VBR).
 // A partition only depends on its predecessor through aoTuV M6's `side_resdef` (:5032-5034): the
 // previous partition's mean magnitude/angle residue difference of the coupled pair.  When the
 // coupling steps of the mapping use disjoint channels (stereo: one step) that number depends
@@ -286,7 +286,7 @@ __global__ void k_couple_quantize(vbm_batch b, int nchunks)
     const vbm_psy *p = &s->psy[b.block_mode];
     const vbm_map *vi = &s->map[b.W];
     const int ch = b.ch;
-    const int blobno = VBM_PACKETBLOBS / 2;
+    const int blobno = b.blobno;
     const int n = p->n;
     const int partition = (p->normal_p ? p->normal_partition : 16);
     const int limit = s->coupling_pointlimit[p->blockflag][blobno];
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(FP * FPC) void k_couple_fast(vbm_batch b)
     const vbm_setup *s = b.setup;
     const vbm_psy *p = &s->psy[b.block_mode];
     const vbm_map *vi = &s->map[b.W];
-    const int blobno = VBM_PACKETBLOBS / 2;
+    const int blobno = b.blobno;
     const size_t SW = b.slab_words;
     const int NCH = (MODE == 1) ? 2 : 1;
     fast_consts c;

@@ -137,6 +137,10 @@ struct vbm_setup {
     int coupling_prepointamp[VBM_PACKETBLOBS], coupling_postpointamp[VBM_PACKETBLOBS];
     int sliding_lowpass[2][VBM_PACKETBLOBS];
     float ampmax_att_per_sec;
+    // bitrate_manager_info (reference lib/bitrate.h:41-50); managed = hi.managed (lib/vorbisenc.c:1037)
+    int managed;
+    long long bi_avg_rate, bi_min_rate, bi_max_rate, bi_reservoir_bits;
+    double bi_reservoir_bias, bi_slew_damp;
     // static tables
     double stereo_threshholds[9], stereo_threshholds_X[9];
     int stn_compand[VBM_NOISE_COMPAND_LEVELS];

@@ -75,6 +75,9 @@ struct Pack {
     }
     const int *i32(const std::string &n, size_t *c = nullptr) const { return get<int>(n, VPK_I32, c); }
     const float *f32(const std::string &n, size_t *c = nullptr) const { return get<float>(n, VPK_F32, c); }
+    const long long *i64(const std::string &n, size_t *c = nullptr) const { return get<long long>(n, VPK_I64, c); }
+    const double *f64(const std::string &n, size_t *c = nullptr) const { return get<double>(n, VPK_F64, c); }
+    bool has(const std::string &n) const { size_t nn = 0; return vpk_get(&f, n.c_str(), VPK_I32, &nn) != nullptr; }
 };
 
 // ---- tone curves (lib/psy.c:171-350) ---------------------------------------------------
@@ -609,6 +612,14 @@ vbm_setup_host *vbm_setup_host_load(const char *common_path, const char *mode_pa
             memcpy(s.coupling_postpointamp, mode.i32("psy_g/coupling_postpointamp"), sizeof(s.coupling_postpointamp));
             memcpy(s.sliding_lowpass, mode.i32("psy_g/sliding_lowpass"), sizeof(s.sliding_lowpass));
             s.ampmax_att_per_sec = mode.f32("psy_g/floats")[2];
+            s.managed = mode.has("info/managed") ? *mode.i32("info/managed") : 0;
+            if (s.managed) {   // lib/vorbisenc.c:890-901
+                const long long *r = mode.i64("bi/rates");
+                const double *d = mode.f64("bi/floats");
+                s.bi_avg_rate = r[0]; s.bi_min_rate = r[1]; s.bi_max_rate = r[2]; s.bi_reservoir_bits = r[3];
+                s.bi_reservoir_bias = d[0];
+                s.bi_slew_damp = d[1];
+            }
         }
         int eighth = *mode.i32("psy_g/eighth_octave_lines");
 

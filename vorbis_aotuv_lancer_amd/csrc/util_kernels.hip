@@ -69,7 +69,7 @@ int from_tiled(const T *src, T *dst, int ncols, int rows, size_t slab, hipStream
 
 // carried encoder state of the listed streams back to its initial values (vorbis_analysis_init,
 // lib/block.c:306-344; _vp_global_look ampmax -9999): one lane per (listed stream, channel)
-__global__ void k_reset_streams(vbm_stream_state st, const int *__restrict__ ids, int n)
+__global__ void k_reset_streams(vbm_stream_state st, const int *__restrict__ ids, int n, long long bm_fill)
 {
     const int lane = blockIdx.x * blockDim.x + threadIdx.x;
     if (lane >= n * st.ch) return;
@@ -84,15 +84,18 @@ __global__ void k_reset_streams(vbm_stream_state st, const int *__restrict__ ids
         st.lW_block_mode[s] = 0;
         st.lW_no[s] = 0;
         st.impadnum[s] = 0;
+        st.bm_avg_reservoir[s] = bm_fill;
+        st.bm_minmax_reservoir[s] = bm_fill;
+        st.bm_avgfloat[s] = (double)(VBM_PACKETBLOBS / 2);
     }
 }
 
 }  // namespace
 
-extern "C" int vbm_launch_reset_streams(const vbm_stream_state *st, const int *d_ids, int n, hipStream_t q)
+extern "C" int vbm_launch_reset_streams(const vbm_stream_state *st, const int *d_ids, int n, long long bm_fill, hipStream_t q)
 {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_reset_streams, dim3((unsigned)((n * st->ch + 63) / 64)), dim3(64), 0, q, *st, d_ids, n);
+    hipLaunchKernelGGL(k_reset_streams, dim3((unsigned)((n * st->ch + 63) / 64)), dim3(64), 0, q, *st, d_ids, n, bm_fill);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

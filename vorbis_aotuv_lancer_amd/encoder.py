@@ -101,13 +101,23 @@ class Encoder:
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         check(lib.vbm_encoder_fetch(self._h, name.encode(), None, C.byref(rows), C.byref(kind), st), "vbm_encoder_fetch")
         dt = torch.float32 if kind.value == b"f" else torch.int32
-        per_sb = name in ("global_ampmax", "packet_bytes")
+        per_sb = name in ("global_ampmax", "packet_bytes", "choice")
         count = nsb if per_sb else nsb * self.setup.channels
         shape = (count,) if rows.value == 1 else (count, rows.value)
         out = torch.empty(shape, dtype=dt, device=dev)
         check(lib.vbm_encoder_fetch(self._h, name.encode(), out.data_ptr(), C.byref(rows), C.byref(kind), st),
               "vbm_encoder_fetch")
         return out
+
+    def fetch_blob(self, k):
+        """Managed bitrate: packetblob k of the last batch before the bitrate manager chose
+        (packets uint8 [nsb, max_bytes], nbytes int32 [nsb])."""
+        nsb, dev = self._last
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        packets = torch.empty((nsb, self.max_packet_bytes), dtype=torch.uint8, device=dev)
+        nbytes = torch.empty((nsb,), dtype=torch.int32, device=dev)
+        check(lib.vbm_encoder_fetch_blob(self._h, k, packets.data_ptr(), nbytes.data_ptr(), st), "vbm_encoder_fetch_blob")
+        return packets, nbytes
 
     def set_sub_batches(self, n):
         """Slices of a batch that run on separate internal HIP streams after the transforms."""
