@@ -132,6 +132,9 @@ def main():
     ap.add_argument("--from-pcm", action="store_true",
                     help="time the whole encoder from raw PCM (stream front end: envelope search + block "
                          "carve-out on the device, SURVEY 8f N1) instead of the per-block path alone")
+    ap.add_argument("--bitrate", type=int, default=0,
+                    help="managed-bitrate setup of this nominal rate (vorbis_encode_init, SURVEY 8f N2: all 15 "
+                         "packetblobs per block) instead of the q5 VBR setup of the headline metric")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -152,7 +155,7 @@ def main():
 
     import vorbis_aotuv_lancer_amd as v
 
-    setup = v.Setup(CHANNELS, RATE, QUALITY)
+    setup = v.Setup(CHANNELS, RATE, bitrate=args.bitrate) if args.bitrate else v.Setup(CHANNELS, RATE, QUALITY)
     blocks = synth_blocks(dev, seed=1234 + rank)      # resident in HBM before timing starts
     LONG = 3
     # The 16384 streams of a step are submitted as SPLIT sub-batches, each to its own encoder object
@@ -328,6 +331,9 @@ def main():
                 "stages": list(stage_ms.keys()),
                 "pipeline_complete": True,
                 "from_pcm": bool(args.from_pcm),
+                **({"managed_bitrate": args.bitrate,
+                    "note": "NOT the headline setup: managed bitrate, 15 packetblobs per block (lib/mapping0.c:1204)"}
+                   if args.bitrate else {}),
                 **({"blocks_encoded": round_count[1], "rounds": round_count[0], "max_rounds_per_write": MAX_ROUNDS}
                    if args.from_pcm else {}),
                 "block_switching": ("in the timed region: PCM intake, envelope search and block carve-out run on the "
