@@ -81,3 +81,12 @@ def test_managed_min_max_from_pcm_with_silence(oracle, cuda):
     for s in (1, 3):
         sigs[s][:, 44100:3 * 44100] = 0
     frontend_vs_oracle(oracle, cuda, 2, 44100, None, NS=4, seconds=4.0, bitrate=(144000, 128000, 112000), sigs=sigs)
+
+
+@pytest.mark.parametrize("ch,rate,bitrate,secs", [
+    (1, 44100, 64000, 2.0),       # uncoupled, residue 1
+    (6, 48000, 320000, 1.7),      # 5.1: several coupling steps (general couple kernel), two submaps
+    (2, 22050, 56000, 3.0),       # low rate: 512/1024 blocks, no M3
+])
+def test_managed_other_classes_from_pcm(oracle, cuda, ch, rate, bitrate, secs):
+    frontend_vs_oracle(oracle, cuda, ch, rate, None, NS=4, seconds=secs, bitrate=bitrate)
