@@ -560,14 +560,24 @@ __global__ void k_tm_stamp(vbm_batch b, int nchunks)
             // the curve values are loaded eight at a time ahead of the stamps (measured: issuing the eight
             // atomics without branches, with no-op stamps for the missing points, is slower — the stamps are
             // bound by atomic throughput, not by the waits the compiler puts between them)
+            // The seeds' current values are read with the curve values, and the atomic is only issued where
+            // it would raise the seed (they only ever grow, so a stale read costs a redundant atomic, never a
+            // missed one): most stamps of the weaker groups lose against a neighbouring peak.
             for (int i = (int)posts[0]; i < post1 && seedptr < tn; i += 8) {
                 float cv[8];
+                int cur[8];
 #pragma unroll
                 for (int u = 0; u < 8; u++) cv[u] = curve[(i + u < post1) ? i + u : post1 - 1];
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
+                    const int sp = seedptr + u * linesper;
+                    cur[u] = T(seed, (sp > 0 && sp < tn) ? sp : 1);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
                     if (i + u < post1 && seedptr < tn) {
-                        if (seedptr > 0) atomicMax(&T(seed, seedptr), seed_key(max + cv[u]));
+                        const int key = seed_key(max + cv[u]);
+                        if (seedptr > 0 && key > cur[u]) atomicMax(&T(seed, seedptr), key);
                         seedptr += linesper;
                     }
                 }
