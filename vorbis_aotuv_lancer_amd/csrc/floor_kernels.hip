@@ -188,6 +188,7 @@ __global__ void k_floor_fit(vbm_batch b, int lpw)
     // hoist these loads over the stores in the loops)
     const float maxover = info->maxover, maxunder = info->maxunder, maxerr = info->maxerr;
     const float twofitweight = info->twofitweight;
+    const int imaxover = (int)floorf(maxover), imaxunder = (int)floorf(maxunder);   // both >= 0 in every floor template
     int i, j;
     int nonzero = 0;
 
@@ -214,14 +215,21 @@ __global__ void k_floor_fit(vbm_batch b, int lpw)
         a->x0 = x0;
         a->x1 = x1;
         if (x1 >= n) x1 = n - 1;
-        for (i = x0; i <= x1; i++) {
-            const int w = qf_get(qf, i);
-            const int quantized = w & 0x7fff;
-            if (quantized) {
-                if (w & 0x8000) {
-                    xa += i; ya += quantized; x2a += i * i; xya += i * quantized; na++;
-                } else {
-                    xb += i; yb += quantized; x2b += i * i; xyb += i * quantized; nb++;
+        // eight bins per 16-byte load, unpacked with constant shifts
+        for (int blk = x0 >> 3; blk <= x1 >> 3; blk++) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(qf.row + (blk << 3));
+            const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                i = (blk << 3) + u;
+                const int w = (int)((wd[u >> 1] >> ((u & 1) * 16)) & 0xffffu);
+                const int quantized = w & 0x7fff;
+                if ((unsigned)(i - x0) <= (unsigned)(x1 - x0) && quantized) {
+                    if (w & 0x8000) {
+                        xa += i; ya += quantized; x2a += i * i; xya += i * quantized; na++;
+                    } else {
+                        xb += i; yb += quantized; x2b += i * i; xyb += i * quantized; nb++;
+                    }
                 }
             }
         }
@@ -288,26 +296,35 @@ __global__ void k_floor_fit(vbm_batch b, int lpw)
                             if (y + maxover < val) split = 1;
                             if (y - maxunder > val) split = 1;
                         }
-                        if (split < 0) {
-                            while (++x < hx) {
-                                err = err + ady;
-                                if (err >= adx) {
-                                    err -= adx;
-                                    y += sy;
-                                } else {
-                                    y += base;
-                                }
-                                wv = qf_get(qf, x);
-                                val = wv & 0x7fff;
-                                mse += ((y - val) * (y - val));
-                                cnt++;
-                                if (wv & 0x8000) {
-                                    if (val) {
-                                        if (y + maxover < val) { split = 1; break; }
-                                        if (y - maxunder > val) { split = 1; break; }
+                        if (split < 0 && lx + 1 < hx) {
+                            // bins lx+1 .. hx-1 in groups of eight (one 16-byte load each).  y, val are integers,
+                            // so  y + maxover < val  <=>  val - y > floor(maxover)  and  y - maxunder > val  <=>
+                            // y - val > floor(maxunder)  (thresholds >= 0): integer compares.  After a violation
+                            // mse / cnt are never read (split = 1), so the group is simply abandoned.
+                            const int xlo = lx + 1, xhi = hx - 1;
+                            for (int blk = xlo >> 3; blk <= xhi >> 3 && split < 0; blk++) {
+                                const uint4 v = *reinterpret_cast<const uint4 *>(qf.row + (blk << 3));
+                                const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                                for (int u = 0; u < 8; u++) {
+                                    x = (blk << 3) + u;
+                                    if ((unsigned)(x - xlo) <= (unsigned)(xhi - xlo)) {
+                                        err = err + ady;
+                                        if (err >= adx) {
+                                            err -= adx;
+                                            y += sy;
+                                        } else {
+                                            y += base;
+                                        }
+                                        wv = (int)((wd[u >> 1] >> ((u & 1) * 16)) & 0xffffu);
+                                        val = wv & 0x7fff;
+                                        const int d = y - val;
+                                        mse += d * d;
+                                        if ((wv & 0x8000) && val && (-d > imaxover || d > imaxunder)) split = 1;
                                     }
                                 }
                             }
+                            cnt += xhi - xlo + 1;
                         }
                         if (split < 0) {
                             if (maxover * maxover / cnt > maxerr) split = 0;
