@@ -106,6 +106,7 @@ __global__ void k_prologue(vbm_batch b)
 //   k_nm_post          compander, M2 post-echo, M8, M9: independent per normal-partition, sliced
 //                      over blockIdx.y in units of partitions.
 #define HY_PF 16
+#define NM_C 16     // checkpoint interval of the five running sums (rows NM_C-1, 2*NM_C-1, ... are stored)
 
 struct hy_bounds { int i1, i2, f1, f2; };
 
@@ -132,6 +133,7 @@ __device__ __forceinline__ void prefix_chain(const vbm_batch &b, const vbm_psy *
     float acc = 0.f, x = 0.f;
     double hi_th = 0;
     const int n25p = p->n25p, n75p = p->n75p;
+    const int rb = p->hy_rb;
 
     for (int i = 0; i < n; i += HY_PF) {
         float fv[HY_PF];
@@ -163,7 +165,9 @@ __device__ __forceinline__ void prefix_chain(const vbm_batch &b, const vbm_psy *
                     if (CHAIN == 3) acc += w * y;
                     if (CHAIN == 4) acc += w * x * y;
                 }
-                T(dst, (i + u) * 5) = acc;
+                // kept: the rows mirrored window edges read directly, and every NM_C-th row as a checkpoint
+                // the solve restarts its running sums from (k_nm_solve)
+                if (i + u < rb || ((i + u) & (NM_C - 1)) == NM_C - 1) T(dst, (i + u) * 5) = acc;
                 x += 1.f;
             }
         }
@@ -204,27 +208,73 @@ __global__ void k_nm_prefix(vbm_batch b)
     }
 }
 
-// window sums and the regression terms of one bin (lib/psy.c:3549-3560 mirrored, :3571-3582 plain)
+// The solve needs the five running sums at the two edges of every bin's window.  The edges only move
+// forward with the bin index, so instead of reading stored sums (five floats per edge per bin, 20 loads per
+// bin in pass 2: 4.4 GB per step through HBM) each edge keeps ITS OWN running sums in registers and adds the
+// terms of the bins it passes — the same additions in the same order as k_nm_prefix, hence the same bits.
+// A slice of bins starts its edges from the nearest stored checkpoint row below (every NM_C-th row); rows
+// below hy_rb are all stored, for the mirrored edges (-lo) of the first bins, which move backwards.
+struct acc5 { float n, x, xx, y, xy; int pos; };   // sums after bin `pos`
 struct hy_abd { float A, B, D; };
-__device__ __forceinline__ hy_abd hybrid_abd(const float *__restrict__ sum, const size_t tb, const int n, const int lo,
-                                             const int hi, const bool mirror)
+
+__device__ __forceinline__ void acc_load(acc5 &a, const float *__restrict__ sum, const size_t tb, const int k)
 {
-    (void)n;
-    const int lo_ = mirror ? -lo : lo;
-    const float *__restrict__ H = sum + tb + (size_t)hi * 5 * 64, *__restrict__ L = sum + tb + (size_t)lo_ * 5 * 64;
-    const float nh = H[0], xh = H[64], xxh = H[128], yh = H[192], xyh = H[256];
-    const float nl = L[0], xl = L[64], xxl = L[128], yl = L[192], xyl = L[256];
+    const float *__restrict__ R = sum + tb + (size_t)k * 5 * 64;
+    a.n = R[0]; a.x = R[64]; a.xx = R[128]; a.y = R[192]; a.xy = R[256];
+    a.pos = k;
+}
+
+// sums after bin `target` (lib/psy.c:3509-3541 for the terms; k >= 1 here: row 0 is always stored)
+template <int PASS>
+__device__ __forceinline__ void acc_seek(acc5 &a, const int target, const float *__restrict__ src,
+                                         const float *__restrict__ sum, const size_t tb, const int rb)
+{
+    const float offset = (PASS == 1) ? 140.f : 0.f;
+    if (target < rb) { acc_load(a, sum, tb, target); return; }
+    if (a.pos < 0 || target < a.pos || target - a.pos >= 2 * NM_C) acc_load(a, sum, tb, ((target + 1) & ~(NM_C - 1)) - 1);
+    while (a.pos < target) {
+        const int k = ++a.pos;
+        float y = src[tb + (size_t)k * 64] + offset;
+        if (y < 1.f) y = 1.f;
+        const float w = y * y, xk = (float)k;
+        a.n += w;
+        a.x += w * xk;
+        a.xx += w * xk * xk;
+        a.y += w * y;
+        a.xy += w * xk * y;
+    }
+}
+
+// window sums and the regression terms of one bin (lib/psy.c:3549-3560 mirrored, :3571-3582 plain)
+__device__ __forceinline__ hy_abd hybrid_abd(const acc5 &H, const acc5 &L, const bool mirror)
+{
     float tN, tX, tXX, tY, tXY;
     if (mirror) {
-        tN = nh + nl; tX = xh - xl; tXX = xxh + xxl; tY = yh + yl; tXY = xyh - xyl;
+        tN = H.n + L.n; tX = H.x - L.x; tXX = H.xx + L.xx; tY = H.y + L.y; tXY = H.xy - L.xy;
     } else {
-        tN = nh - nl; tX = xh - xl; tXX = xxh - xxl; tY = yh - yl; tXY = xyh - xyl;
+        tN = H.n - L.n; tX = H.x - L.x; tXX = H.xx - L.xx; tY = H.y - L.y; tXY = H.xy - L.xy;
     }
     hy_abd r;
     r.A = tY * tXX - tX * tXY;
     r.B = tN * tXY - tX * tY;
     r.D = tN * tXX - tX * tX;
     return r;
+}
+
+// one window: edges hi and lo (mirror: the lower edge is the stored row -lo)
+template <int PASS>
+__device__ __forceinline__ hy_abd hybrid_window(acc5 &H, acc5 &L, const int lo, const int hi, const bool mirror,
+                                                const float *__restrict__ src, const float *__restrict__ sum,
+                                                const size_t tb, const int rb)
+{
+    acc_seek<PASS>(H, hi, src, sum, tb, rb);
+    if (mirror) {
+        acc5 M;
+        acc_load(M, sum, tb, -lo);
+        return hybrid_abd(H, M, true);
+    }
+    acc_seek<PASS>(L, lo, src, sum, tb, rb);
+    return hybrid_abd(H, L, false);
 }
 
 template <int PASS>
@@ -240,27 +290,38 @@ __global__ void k_nm_solve(vbm_batch b, int nchunks)
     const int fixed = (PASS == 1) ? -1 : p->noisewindowfixed;
     const hy_bounds h = hybrid_bounds(p, fixed);
     const int *__restrict__ bark_lo = p->bark_lo, *__restrict__ bark_hi = p->bark_hi;   // hoisted: see note at psy_of
+    const int rb = p->hy_rb;
     const float *__restrict__ sum = b.sumT;
     float *__restrict__ noise = b.noiseT;
     float *__restrict__ work = b.workT;
+    // pass 2 reads `work` along its window edges (bins of other slices), so its own result
+    // logmdct - work (lib/psy.c:3812) goes to a second array: logmaskT is free until _vp_offset_and_mix
+    float *__restrict__ work2 = b.logmaskT;
     const float *__restrict__ logmdct = b.logmdctT;
+    const float *__restrict__ src = (PASS == 1) ? b.logmdctT : b.workT;   // what k_nm_prefix<PASS> summed
 
     // the tail loops (lib/psy.c:3587-3591, :3631-3635) keep A, B, D of the last bin solved before them
     hy_abd tail; tail.A = 0.f; tail.B = 0.f; tail.D = 1.f;
     if (c1 > h.i2 && h.i2 > 0) {
         const int t = h.i2 - 1;
-        tail = hybrid_abd(sum, tb, n, bark_lo[t], bark_hi[t], t < h.i1);
+        acc5 Ht, Lt;
+        Ht.pos = Lt.pos = -1;
+        tail = hybrid_window<PASS>(Ht, Lt, bark_lo[t], bark_hi[t], t < h.i1, src, sum, tb, rb);
     }
     hy_abd ftail = tail;
     if (fixed > 0 && c1 > h.f2 && h.f2 > 0) {
         const int t = h.f2 - 1, hi = t + fixed / 2, lo = hi - fixed;
-        ftail = hybrid_abd(sum, tb, n, lo, hi, t < h.f1);
+        acc5 Ht, Lt;
+        Ht.pos = Lt.pos = -1;
+        ftail = hybrid_window<PASS>(Ht, Lt, lo, hi, t < h.f1, src, sum, tb, rb);
     }
 
+    acc5 H, L, HF, LF;
+    H.pos = L.pos = HF.pos = LF.pos = -1;
     for (int i = c0; i < c1; i++) {
         const float x = (float)i;   // the source's x += 1.f from 0 is exact below 2^24
         hy_abd v = tail;
-        if (i < h.i2) v = hybrid_abd(sum, tb, n, bark_lo[i], bark_hi[i], i < h.i1);
+        if (i < h.i2) v = hybrid_window<PASS>(H, L, bark_lo[i], bark_hi[i], i < h.i1, src, sum, tb, rb);
         float R = (v.A + x * v.B) / v.D;
         if (R < 0.f) R = 0.f;
         float nz = R - offset;
@@ -272,13 +333,13 @@ __global__ void k_nm_solve(vbm_batch b, int nchunks)
                 hy_abd w = ftail;
                 if (i < h.f2) {
                     const int hi = i + fixed / 2, lo = hi - fixed;
-                    w = hybrid_abd(sum, tb, n, lo, hi, i < h.f1);
+                    w = hybrid_window<PASS>(HF, LF, lo, hi, i < h.f1, src, sum, tb, rb);
                 }
                 R = (w.A + x * w.B) / w.D;
                 if (R - offset < nz) nz = R - offset;
             }
             T(noise, i) = nz;
-            T(work, i) = T(logmdct, i) - T(work, i);            // lib/psy.c:3812
+            T(work2, i) = T(logmdct, i) - T(work, i);           // lib/psy.c:3812
         }
     }
 }
@@ -388,7 +449,7 @@ __global__ void k_nm_ntfix(vbm_batch b)
 {
     const int lane = blockIdx.x * blockDim.x + threadIdx.x;
     if (lane >= b.ncb) return;
-    ntfix(b, psy_of(b), lane, b.logmdctT, b.workT);
+    ntfix(b, psy_of(b), lane, b.logmdctT, b.logmaskT);   // pass 2's logmdct - work: see k_nm_solve
 }
 
 __global__ void k_nm_post(vbm_batch b, int nchunks)
@@ -408,7 +469,7 @@ __global__ void k_nm_post(vbm_batch b, int nchunks)
     const int c0 = k0 * partition, c1 = VMIN(k1 * partition, n);
     int i, j, k;
 
-    float *logmdct = b.logmdctT, *logmask = b.noiseT, *work = b.workT, *epeak = b.epeakT, *npeak = b.npeakT;
+    float *logmdct = b.logmdctT, *logmask = b.noiseT, *work = b.logmaskT /* k_nm_solve<2> */, *epeak = b.epeakT, *npeak = b.npeakT;
     const float noise_compand_level = b.st.lowcomp[col];
     const float *__restrict__ noisecompand = p->noisecompand, *__restrict__ noisecompand_high = p->noisecompand_high;
     const int *__restrict__ stn_compand = s->stn_compand;

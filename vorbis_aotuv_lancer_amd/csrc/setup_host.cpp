@@ -682,6 +682,16 @@ vbm_setup_host *vbm_setup_host_load(const char *common_path, const char *mode_pa
                     }
                     p.hy_f2 = k;
                 }
+                // mirrored window edges read the sums at -lo: every row below this bound is kept (psy_kernels.hip)
+                int rb = 1;
+                for (k = 0; k < p.hy_i1; k++)
+                    if (-t.bark_lo[k] + 1 > rb) rb = -t.bark_lo[k] + 1;
+                for (k = 0; k < p.hy_f1; k++) {
+                    int lo = k + fixed / 2 - fixed;
+                    if (-lo + 1 > rb) rb = -lo + 1;
+                }
+                p.hy_rb = (rb + 15) & ~15;
+                if (p.hy_rb > n) p.hy_rb = n;
             }
         }
 
