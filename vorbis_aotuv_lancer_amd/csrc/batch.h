@@ -93,6 +93,7 @@ struct vbm_batch {
     int *choice;                    // [Ls] bm->choice of the block
     int pack_submaps;               // residue submaps of this block type and their partition counts (host copy)
     int pack_partvals[16];
+    int pack_spp[16];               // samples per partition (residue grouping) of each submap
 };
 
 #ifdef __HIPCC__

@@ -410,6 +410,7 @@ static void configure(vbm_encoder *e, vbm_batch &b, int block_mode, int nsb, con
         for (int i = 0; i < m.submaps && i < 16; i++) {
             const vbm_residue &r = s->residue[m.residuesubmap[i]];
             b.pack_partvals[i] = (r.end - r.begin) / r.grouping;
+            b.pack_spp[i] = r.grouping;
         }
     }
 }

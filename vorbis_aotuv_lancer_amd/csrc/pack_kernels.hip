@@ -92,6 +92,8 @@ struct book_regs {
     const signed char *lengthlist;
     const uint32_t *codelist;
     const int *used_point, *used_index;
+    const short *used_pack;
+    const int *used_norm;
 };
 __device__ __forceinline__ book_regs load_book(const vbm_book *book)
 {
@@ -100,6 +102,7 @@ __device__ __forceinline__ book_regs load_book(const vbm_book *book)
     r.used = book->used; r.entries = book->entries;
     r.lengthlist = book->lengthlist; r.codelist = book->codelist;
     r.used_point = book->used_point; r.used_index = book->used_index;
+    r.used_pack = book->used_pack; r.used_norm = book->used_norm;
     return r;
 }
 
@@ -139,19 +142,49 @@ __device__ __forceinline__ int besterror(const book_regs *book, int *a)
     }
 
     if (book->lengthlist[index] <= 0) {
-        int best = -1;
-        const int *pt = book->used_point;
-        for (i = 0; i < book->used; i++, pt += dim) {
-            int dist = 0;
-            for (j = 0; j < dim; j++) {
-                int val = pt[j] - a[j];
-                dist += val * val;
+        // exhaustive search over the entries that have a codeword, first minimum wins (lib/res0.c:343-370).
+        // |pt - a|^2 = |pt|^2 - 2 pt.a + |a|^2: the last term is common, so entries are compared by
+        // |pt|^2 - 2 pt.a (same order, same ties); pt.a as packed 16-bit dot products, one 16-byte
+        // load per entry.  Only the winner's index is tracked; its point is fetched afterwards.
+        const int used = book->used;
+        int bi = 0;
+        bool small = book->used_pack != nullptr;
+        for (j = 0; j < dim; j++) small = small && (a[j] >= -32768 && a[j] <= 32767);
+        if (small) {
+            typedef short short2v __attribute__((ext_vector_type(2)));
+            uint32_t pa[4] = {0u, 0u, 0u, 0u};
+            for (j = 0; j < dim; j++) pa[j >> 1] |= ((uint32_t)a[j] & 0xffffu) << ((j & 1) * 16);
+            const uint4 *pk = reinterpret_cast<const uint4 *>(book->used_pack);
+            const int *__restrict__ nrm = book->used_norm;
+            const int words = (dim + 1) >> 1;
+            int best = 0;
+            for (i = 0; i < used; i++) {
+                const uint4 v = pk[i];
+                int dot = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, v.x), __builtin_bit_cast(short2v, pa[0]), 0, false);
+                if (words > 1) dot = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, v.y), __builtin_bit_cast(short2v, pa[1]), dot, false);
+                if (words > 2) {
+                    dot = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, v.z), __builtin_bit_cast(short2v, pa[2]), dot, false);
+                    dot = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, v.w), __builtin_bit_cast(short2v, pa[3]), dot, false);
+                }
+                const int score = nrm[i] - 2 * dot;
+                if (i == 0 || score < best) { best = score; bi = i; }
             }
-            if (best == -1 || dist < best) {
-                for (j = 0; j < dim; j++) p[j] = pt[j];
-                best = dist;
-                index = book->used_index[i];
+        } else {
+            int best = -1;
+            const int *pt = book->used_point;
+            for (i = 0; i < used; i++, pt += dim) {
+                int dist = 0;
+                for (j = 0; j < dim; j++) {
+                    int val = pt[j] - a[j];
+                    dist += val * val;
+                }
+                if (best == -1 || dist < best) { best = dist; bi = i; }
             }
+        }
+        if (used > 0) {
+            const int *pt = book->used_point + (size_t)bi * dim;
+            for (j = 0; j < dim; j++) p[j] = pt[j];
+            index = book->used_index[bi];
         }
     }
 
@@ -483,8 +516,7 @@ __device__ __forceinline__ void res_classify(const vbm_batch &b, const res_view 
     int i, j, k;
 
     if (r->type == 2) {
-        // _2class (lib/res0.c:473-526) and the interleave of res2_forward (:781-787) for these partitions
-        int *work = b.workvqT + SBT(sb);
+        // _2class (lib/res0.c:473-526)
         const int nb = v.nb;
         const int lsteps = (v.spp + nb - 1) / nb;   // the source advances l once per nb samples of a partition
         for (i = i0; i < i1; i++) {
@@ -501,15 +533,6 @@ __device__ __forceinline__ void res_classify(const vbm_batch &b, const res_view 
             for (j = 0; j < possible_partitions - 1; j++)
                 if (magmax <= classmetric1[j] && angmax <= classmetric2[j]) break;
             PW(0, i) = j;
-        }
-        // interleaved vector work[x] = in[x % nb][x / nb] over these partitions' samples
-        {
-            const int xa = rbegin + i0 * v.spp, xb = rbegin + i1 * v.spp;
-            int l = xa / nb, k = xa - l * nb;               // one division, then counted up
-            for (int x = xa; x < xb; x++) {
-                work[(size_t)x * 64] = IWC(v.chlist[k], l);
-                if (++k == nb) { k = 0; l++; }
-            }
         }
     } else {
         // _01class (lib/res0.c:406-468): only the nonzero channels take part (:715-745)
@@ -534,6 +557,7 @@ __device__ __forceinline__ void res_classify(const vbm_batch &b, const res_view 
 
 __global__ void k_res_vq(vbm_batch b, int sm, int nchunks)
 {
+    extern __shared__ int vq_lds[];   // [samples per partition][64 lanes]
     const int sb = blockIdx.x * blockDim.x + threadIdx.x;
     if (sb >= b.nsb) return;
     const vbm_setup *s = b.setup;
@@ -548,13 +572,28 @@ __global__ void k_res_vq(vbm_batch b, int sm, int nchunks)
     const int *partword = b.partwordT + SBT(sb);
     int *lenT = b.vqlenT + SBT(sb);
     uint64_t *slot = b.vqcodeT + (size_t)(sb >> 6) * b.vq_slab_words + (sb & 63);
-    int *work = b.workvqT + SBT(sb);
     const int veclen = (r->type == 2) ? b.n * v.nb : b.n;
     const size_t stage_slots = (size_t)b.n * b.ch;
+    // The samples of one partition are staged in LDS ([sample][lane]: conflict-free) and the cascade runs
+    // there: the loads of a partition are all in flight together, and the remainder a stage leaves for the
+    // next never goes through global memory (the in-place updates of lib/res0.c:372-375 made every vector's
+    // loads wait for the previous vector's stores).  res2's interleaved vector (lib/res0.c:781-787) is
+    // formed by the load itself; nothing reads the remainder after the last stage, so it is not written back.
+    int *stage = vq_lds + threadIdx.x;
+    const int spp = v.spp, nb = v.nb, rbegin = r->begin;
 
     for (int i = i0; i < i1; i++) {
-        const int offset = i * v.spp + r->begin;
+        const int offset = i * spp + rbegin;
         for (int j = 0; j < v.used; j++) {
+            if (r->type == 2) {
+                int l = offset / nb, k = offset - l * nb;      // work[x] = in[x % nb][x / nb]
+                for (int e = 0; e < spp; e++) {
+                    stage[e * 64] = IWC(v.chlist[k], l);
+                    if (++k == nb) { k = 0; l++; }
+                }
+            } else {
+                for (int e = 0; e < spp; e++) stage[e * 64] = IWC(v.vch[j], offset + e);
+            }
             const int cls = PW(j, i);
             for (int st = 0; st < r->stages; st++) {
                 int bits = 0;
@@ -563,22 +602,14 @@ __global__ void k_res_vq(vbm_batch b, int sm, int nchunks)
                     const book_regs bk = load_book(&s->book[bi]);
                     const book_regs *book = &bk;
                     const int dim = book->dim;
-                    const int step = v.spp / dim;
+                    const int step = spp / dim;
                     uint64_t *sl = slot + (st * stage_slots + (size_t)j * veclen + offset) * 64;
                     for (int t = 0; t < step; t++) {
                         int a[VBM_MAX_BOOK_DIM];
-                        const int x0 = offset + t * dim;
-                        if (r->type == 2) {
-                            for (int d = 0; d < dim; d++) a[d] = work[(size_t)(x0 + d) * 64];
-                        } else {
-                            for (int d = 0; d < dim; d++) a[d] = IWC(v.vch[j], x0 + d);
-                        }
+                        int *src = stage + t * dim * 64;
+                        for (int d = 0; d < dim; d++) a[d] = src[d * 64];
                         const int entry = besterror(book, a);
-                        if (r->type == 2) {
-                            for (int d = 0; d < dim; d++) work[(size_t)(x0 + d) * 64] = a[d];
-                        } else {
-                            for (int d = 0; d < dim; d++) IWC(v.vch[j], x0 + d) = a[d];
-                        }
+                        for (int d = 0; d < dim; d++) src[d * 64] = a[d];
                         uint64_t cw = 0;
                         if (entry >= 0 && entry < book->entries) {
                             const int len = book->lengthlist[entry];
@@ -722,7 +753,8 @@ extern "C" int vbm_launch_pack(const vbm_batch *b, hipStream_t st)
     for (int sm = 0; sm < b->pack_submaps; sm++) {
         int nchunks = b->pack_partvals[sm] < 32 ? b->pack_partvals[sm] : 32;
         if (nchunks < 1) nchunks = 1;
-        hipLaunchKernelGGL(k_res_vq, dim3(tiles, (unsigned)nchunks), dim3(64), 0, st, *b, sm, nchunks);
+        hipLaunchKernelGGL(k_res_vq, dim3(tiles, (unsigned)nchunks), dim3(64), (size_t)b->pack_spp[sm] * 64 * sizeof(int), st, *b,
+                           sm, nchunks);
         hipLaunchKernelGGL(k_res_offsets, dim3(tiles), dim3(64), 0, st, *b, sm);
         hipLaunchKernelGGL(k_res_emit, dim3(tiles, (unsigned)nchunks), dim3(64), 0, st, *b, sm, nchunks);
     }

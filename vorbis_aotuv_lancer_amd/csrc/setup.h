@@ -81,6 +81,10 @@ struct vbm_book {                // static_codebook + encode side of codebook
     int used;
     const int *used_index;           // used
     const int *used_point;           // used x dim
+    // the same points as 8 x int16 per entry (zero-padded past dim; 16 bytes, 16-byte aligned) and their
+    // squared norms, for the packed-dot-product search; NULL if a coordinate does not fit 16 bits
+    const short *used_pack;          // used x 8
+    const int *used_norm;            // used
 };
 
 struct vbm_residue {             // vorbis_info_residue0 + look

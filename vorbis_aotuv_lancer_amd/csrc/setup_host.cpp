@@ -474,6 +474,8 @@ static void rebase_book(vbm_book &b, const unsigned char *base)
     rebase(b.codelist, base);
     rebase(b.used_index, base);
     rebase(b.used_point, base);
+    rebase(b.used_pack, base);
+    rebase(b.used_norm, base);
 }
 
 extern "C" int vbm_host_mdct_trig(int n, float *out);
@@ -561,6 +563,24 @@ vbm_setup_host *vbm_setup_host_load(const char *common_path, const char *mode_pa
             b.used = (int)uidx.size();
             b.used_index = as_off<int>(A.put(uidx));
             b.used_point = as_off<int>(A.put(upt));
+            b.used_pack = nullptr;
+            b.used_norm = nullptr;
+            if (b.used) {
+                std::vector<short> pk((size_t)b.used * 8, 0);
+                std::vector<int> nrm(b.used, 0);
+                bool fits = true;
+                for (int u = 0; u < b.used; u++)
+                    for (int d = 0; d < b.dim; d++) {
+                        const int v = upt[(size_t)u * b.dim + d];
+                        if (v < -32768 || v > 32767) fits = false;
+                        pk[(size_t)u * 8 + d] = (short)v;
+                        nrm[u] += v * v;
+                    }
+                if (fits) {
+                    b.used_pack = as_off<short>(A.put(pk));
+                    b.used_norm = as_off<int>(A.put(nrm));
+                }
+            }
         }
         H->books_off = 0;
 
