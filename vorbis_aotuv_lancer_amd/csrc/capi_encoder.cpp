@@ -381,6 +381,7 @@ static void configure(vbm_encoder *e, vbm_batch &b, int block_mode, int nsb, con
     b.Ls = e->Ls;
     b.pcm = d_pcm;
     b.blobno = VBM_PACKETBLOBS / 2;
+    b.mix_makes_qf = getenv("VBM_SEPARATE_FLOOR_PREP") ? 0 : vbm_mix_can_make_qf(&b);
     {
         // partition slicing of couple/quantise (quant_kernels.hip): allowed when no channel takes part
         // in two coupling steps; lowpass rounding as lib/mapping0.c:778-781

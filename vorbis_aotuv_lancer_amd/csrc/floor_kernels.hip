@@ -568,8 +568,9 @@ extern "C" int vbm_launch_floor_fit(const vbm_batch *b, hipStream_t st)
         lpw = e ? atoi(e) : 64;
         if (lpw < 1 || lpw > 64) lpw = 64;
     }
-    hipLaunchKernelGGL(k_floor_prep, dim3((unsigned)((b->ncb + 63) / 64), (unsigned)((b->n + 63) / 64)), dim3(256), 0,
-                       st, *b);
+    if (!b->mix_makes_qf)   // otherwise k_mix has written qf_bm already (psy_kernels.hip)
+        hipLaunchKernelGGL(k_floor_prep, dim3((unsigned)((b->ncb + 63) / 64), (unsigned)((b->n + 63) / 64)), dim3(256), 0,
+                           st, *b);
     hipLaunchKernelGGL(k_floor_fit, dim3((unsigned)((b->ncb + lpw - 1) / lpw)), dim3(64), 0, st, *b, lpw);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -9,6 +9,7 @@ int vbm_launch_prologue(const vbm_batch *b, hipStream_t st);
 int vbm_launch_noisemask(const vbm_batch *b, hipStream_t st);
 int vbm_launch_tonemask(const vbm_batch *b, hipStream_t st);
 int vbm_launch_mix(const vbm_batch *b, hipStream_t st);
+int vbm_mix_can_make_qf(const vbm_batch *b);
 int vbm_launch_reset_streams(const vbm_stream_state *st, const int *d_ids, int n, long long bm_fill, hipStream_t q);
 int vbm_launch_block_state(const vbm_batch *b, hipStream_t st);   // aoTuV block-state update (after mix)
 int vbm_launch_mix_managed(const vbm_batch *b, int offset_select, hipStream_t st);   // managed bitrate: 1, 2, 0

@@ -792,16 +792,11 @@ struct mod3 {
     float noise_rate, noise_rate_low, noise_center, tone_rate;
 };
 
-// Bins are independent for every block type except impulse short blocks (M3 reads and rewrites
-// tempmdct across bins and updates npeak per partition in bin order), so the launch splits the
-// bin range into `nchunks` slices (blockIdx.y) for block modes 1..3 and uses one slice for mode 0.
-template <int SEL, bool MANAGED>
-__global__ void k_mix(vbm_batch b, int nchunks)
+// QF: also leave the floor fit's input word of every bin (floor_kernels.hip: dBquant(logmask) | test << 15) in
+// the LDS tile qtile[bin - i0][lane]; the kernel writes the tile out as block-major rows.
+template <int SEL, bool MANAGED, bool QF>
+__device__ __forceinline__ void mix_body(const vbm_batch &b, const int nchunks, const int lane, uint16_t (*qtile)[66])
 {
-    const int lane = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lane >= b.ncb) return;
-    // managed bitrate: the hi / lo rate passes run only for channels whose first fit exists (lib/mapping0.c:1097)
-    if (MANAGED && SEL != 1 && !b.post_valid_blob[(size_t)(VBM_PACKETBLOBS / 2) * b.L + lane]) return;
     constexpr bool BUF = (!MANAGED || SEL == 2);   // mp->mdctbuf_flag of set_m3p when the rate is high (lib/psy.c:4165-4173)
     const size_t tb = TB(b, lane);
     const vbm_setup *s = b.setup;
@@ -825,6 +820,7 @@ __global__ void k_mix(vbm_batch b, int nchunks)
     const int impadnum = b.st.impadnum[sid];
     float low_compand = b.st.lowcomp[col];
     const int end_block = s->floor[b.W].info_n;   // vif->n, lib/mapping0.c:1055
+    const float twofitatten = s->floor[s->map[b.W].floorsubmap[s->map[b.W].chmuxlist[c]]].twofitatten;
 
     int i, j, k;
     int hsrate = ((p->rate < 26000) ? 0 : 1);
@@ -996,16 +992,23 @@ __global__ void k_mix(vbm_batch b, int nchunks)
         }
 
         // M4 MAIN
+        float lmv;
         if (val > tval) {
-            T(logmask, i) = val;
+            lmv = val;
         } else if ((i > m4_start) && (i < m4_end)) {
             if (lm < tval) {
                 if (lm < val) tval -= (tval - val) * m4_thres;
                 else tval = lm;
             }
-            T(logmask, i) = tval;
+            lmv = tval;
         } else
-            T(logmask, i) = tval;
+            lmv = tval;
+        T(logmask, i) = lmv;
+        if (QF) {   // vorbis_dBquant (lib/floor1.c:294) and the two-fit test (lib/floor1.c:452)
+            int q = (int)(lmv * 7.3142857f + 1023.5f);
+            q = q > 1023 ? 1023 : (q < 0 ? 0 : q);
+            qtile[i - i0][threadIdx.x] = (uint16_t)(q | ((lm + twofitatten >= lmv) ? 0x8000 : 0));
+        }
 
         // M1 (offset_select == 1)
         if (SEL == 1) {
@@ -1058,6 +1061,32 @@ __global__ void k_mix(vbm_batch b, int nchunks)
 #undef TEMP
 }
 
+// Bins are independent for every block type except impulse short blocks (M3 reads and rewrites
+// tempmdct across bins and updates npeak per partition in bin order), so the launch splits the
+// bin range into `nchunks` slices (blockIdx.y) for block modes 1..3 and uses one slice for mode 0.
+// QF (slices of at most 64 bins): the slice's floor-fit words go out as block-major rows qf_bm[block][n]
+// (what k_floor_prep would compute from logmask and logmdct in a pass of its own).
+template <int SEL, bool MANAGED, bool QF>
+__global__ void k_mix(vbm_batch b, int nchunks)
+{
+    __shared__ uint16_t qtile[QF ? 64 : 1][66];
+    __shared__ uint8_t colact[64];
+    const int lane = blockIdx.x * blockDim.x + threadIdx.x;
+    // managed bitrate: the hi / lo rate passes run only for channels whose first fit exists (lib/mapping0.c:1097)
+    const bool active = lane < b.ncb && !(MANAGED && SEL != 1 && !b.post_valid_blob[(size_t)(VBM_PACKETBLOBS / 2) * b.L + lane]);
+    if (active) mix_body<SEL, MANAGED, QF>(b, nchunks, lane, qtile);
+    if (QF) {
+        colact[threadIdx.x] = active ? 1 : 0;
+        __syncthreads();
+        const int n = b.n;
+        const int i0 = (int)((long)n * blockIdx.y / nchunks), i1 = (int)((long)n * (blockIdx.y + 1) / nchunks);
+        const int k = threadIdx.x, c0 = blockIdx.x * 64;
+        if (k < i1 - i0)
+            for (int c = 0; c < 64; c++)
+                if (colact[c]) b.qf_bm[(size_t)(c0 + c) * n + i0 + k] = qtile[k][c];
+    }
+}
+
 }  // namespace
 
 static inline dim3 grid_for(int lanes) { return dim3((unsigned)((lanes + 63) / 64)); }
@@ -1100,16 +1129,29 @@ extern "C" int vbm_launch_tonemask(const vbm_batch *b, hipStream_t st)
 extern "C" int vbm_launch_mix(const vbm_batch *b, hipStream_t st)
 {
     const int nchunks = (b->block_mode == 0) ? 1 : bin_chunks(b);
-    hipLaunchKernelGGL((k_mix<1, false>), dim3((unsigned)((b->ncb + 63) / 64), (unsigned)nchunks), dim3(64), 0, st, *b, nchunks);
+    const dim3 grid((unsigned)((b->ncb + 63) / 64), (unsigned)nchunks);
+    if (b->mix_makes_qf) hipLaunchKernelGGL((k_mix<1, false, true>), grid, dim3(64), 0, st, *b, nchunks);
+    else hipLaunchKernelGGL((k_mix<1, false, false>), grid, dim3(64), 0, st, *b, nchunks);
     return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+// slices of at most 64 bins fit the 64 x 64 tile k_mix writes the floor-fit words through
+extern "C" int vbm_mix_can_make_qf(const vbm_batch *b)
+{
+    return b->block_mode != 0 && (b->n + bin_chunks(b) - 1) / bin_chunks(b) <= 64;
 }
 // managed bitrate: offset_select 1 (first fit), 2 (higher rate), 0 (lower rate), lib/mapping0.c:1044-1160
 extern "C" int vbm_launch_mix_managed(const vbm_batch *b, int offset_select, hipStream_t st)
 {
     const int nchunks = (b->block_mode == 0) ? 1 : bin_chunks(b);
     const dim3 grid((unsigned)((b->ncb + 63) / 64), (unsigned)nchunks);
-    if (offset_select == 1) hipLaunchKernelGGL((k_mix<1, true>), grid, dim3(64), 0, st, *b, nchunks);
-    else if (offset_select == 2) hipLaunchKernelGGL((k_mix<2, true>), grid, dim3(64), 0, st, *b, nchunks);
-    else hipLaunchKernelGGL((k_mix<0, true>), grid, dim3(64), 0, st, *b, nchunks);
+    if (b->mix_makes_qf) {
+        if (offset_select == 1) hipLaunchKernelGGL((k_mix<1, true, true>), grid, dim3(64), 0, st, *b, nchunks);
+        else if (offset_select == 2) hipLaunchKernelGGL((k_mix<2, true, true>), grid, dim3(64), 0, st, *b, nchunks);
+        else hipLaunchKernelGGL((k_mix<0, true, true>), grid, dim3(64), 0, st, *b, nchunks);
+    } else {
+        if (offset_select == 1) hipLaunchKernelGGL((k_mix<1, true, false>), grid, dim3(64), 0, st, *b, nchunks);
+        else if (offset_select == 2) hipLaunchKernelGGL((k_mix<2, true, false>), grid, dim3(64), 0, st, *b, nchunks);
+        else hipLaunchKernelGGL((k_mix<0, true, false>), grid, dim3(64), 0, st, *b, nchunks);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
