@@ -170,7 +170,8 @@ def main():
     wflags = np.full(per, 3, dtype=np.uint8)   # lW = nW = long
     parts = [[blk[p * per:(p + 1) * per] for blk in blocks] for p in range(SPLIT)]   # contiguous views
 
-    back_queues = [torch.cuda.Stream(device=dev) for _ in range(SPLIT)]
+    back_queues = [torch.cuda.Stream(device=dev, priority=int(os.environ.get("VBM_BENCH_BACK_PRIORITY", "0")))
+                   for _ in range(SPLIT)]
     outs = [[(torch.empty((per, enc.max_packet_bytes), dtype=torch.uint8, device=dev),
               torch.empty((per,), dtype=torch.int32, device=dev)) for _ in range(2)] for _ in range(SPLIT)]
     fe = None

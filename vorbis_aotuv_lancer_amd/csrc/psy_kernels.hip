@@ -1091,7 +1091,16 @@ __global__ void k_mix(vbm_batch b, int nchunks)
 
 static inline dim3 grid_for(int lanes) { return dim3((unsigned)((lanes + 63) / 64)); }
 // slices of the bin range for the kernels whose bins are independent (long blocks: 64 bins each)
-static inline int bin_chunks(const vbm_batch *b) { return b->n >= 1024 ? 16 : b->n >= 512 ? 8 : b->n >= 256 ? 4 : 2; }
+static inline int bin_chunks(const vbm_batch *b)
+{
+    static int big = 0;
+    if (!big) {
+        const char *e = getenv("VBM_BIN_CHUNKS");   // tuning knob: slices of the long-block bin range
+        big = e ? atoi(e) : 16;
+        if (big < 1 || big > 64) big = 16;
+    }
+    return b->n >= 1024 ? big : b->n >= 512 ? 8 : b->n >= 256 ? 4 : 2;
+}
 
 extern "C" int vbm_launch_prologue(const vbm_batch *b, hipStream_t st)
 {
