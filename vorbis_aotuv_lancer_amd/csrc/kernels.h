@@ -19,7 +19,9 @@ int vbm_launch_bitrate_choose(const vbm_batch *b, uint8_t *d_packets, hipStream_
 int vbm_launch_floor_fit(const vbm_batch *b, hipStream_t st);
 int vbm_launch_floor_encode(const vbm_batch *b, hipStream_t st);
 int vbm_launch_couple_quantize(const vbm_batch *b, hipStream_t st);
-int vbm_launch_pack(const vbm_batch *b, hipStream_t st);
+int vbm_launch_pack(const vbm_batch *b, hipStream_t st);          // = pack_head, then pack_residue
+int vbm_launch_pack_head(const vbm_batch *b, hipStream_t st);     // header + floor bits: may run beside couple/quantise
+int vbm_launch_pack_residue(const vbm_batch *b, hipStream_t st);  // after both: nonzero propagation, residue class + VQ + bits
 // tiled [col>>6][rows][64] (tile stride `slab` elements) -> block-major dst[col][rows]
 int vbm_launch_untranspose_f32(const float *srcT, float *dst_bm, int rows, size_t slab, int ncols, hipStream_t st);
 int vbm_launch_untranspose_i32(const int *srcT, int *dst_bm, int rows, size_t slab, int ncols, hipStream_t st);

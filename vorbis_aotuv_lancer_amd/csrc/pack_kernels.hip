@@ -229,6 +229,24 @@ __device__ __forceinline__ res_view residue_view(const vbm_batch &b, const vbm_m
 #define LEN(stg, jv, iv) lenT[(((size_t)(stg) * b.ch + (jv)) * v.partvals + (iv)) * 64]
 #define OFF(stg, jv, iv) offT[(((size_t)(stg) * b.ch + (jv)) * v.partvals + (iv)) * 64]
 
+// nonzero[] after coupling (lib/psy.c:5133-5140); couple/quantise reads the flags as floor1_encode left them, so
+// this runs after it and before the residue kernels
+__global__ void k_nonzero_propagate(vbm_batch b)
+{
+    const int sb = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sb >= b.nsb) return;
+    const vbm_map *info = &b.setup->map[b.W];
+    const size_t col0 = (size_t)sb * b.ch;
+    for (int i = 0; i < info->coupling_steps; i++) {
+        const size_t m = col0 + info->coupling_mag[i], a = col0 + info->coupling_ang[i];
+        if (b.nonzero[m] || b.nonzero[a]) {
+            b.nonzero[m] = 1;
+            b.nonzero[a] = 1;
+        }
+    }
+}
+
+// packet header and the floors' bits: needs floor1_encode's values only, so it may run beside couple/quantise
 __global__ void k_pack_head(vbm_batch b)
 {
     const int sb = blockIdx.x * blockDim.x + threadIdx.x;
@@ -239,15 +257,6 @@ __global__ void k_pack_head(vbm_batch b)
     const int ch = b.ch;
     const size_t col0 = (size_t)sb * ch;
     int i, j, k;
-
-    // nonzero[] after coupling (lib/psy.c:5133-5140); couple/quantise left the flags untouched
-    for (i = 0; i < info->coupling_steps; i++) {
-        const size_t m = col0 + info->coupling_mag[i], a = col0 + info->coupling_ang[i];
-        if (b.nonzero[m] || b.nonzero[a]) {
-            b.nonzero[m] = 1;
-            b.nonzero[a] = 1;
-        }
-    }
 
     BitW w;
     w.base = (uint32_t *)b.packetT + (size_t)(sb >> 6) * (b.max_packet_bytes / 4) * 64 + (sb & 63);
@@ -745,11 +754,18 @@ extern "C" int vbm_launch_bitrate_choose(const vbm_batch *b, uint8_t *d_packets,
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-extern "C" int vbm_launch_pack(const vbm_batch *b, hipStream_t st)
+extern "C" int vbm_launch_pack_head(const vbm_batch *b, hipStream_t st)
 {
     const unsigned tiles = (unsigned)((b->nsb + 63) / 64);
     if (hipMemsetAsync(b->packetT, 0, (size_t)tiles * 64 * b->max_packet_bytes, st) != hipSuccess) return -2;
     hipLaunchKernelGGL(k_pack_head, dim3(tiles), dim3(64), 0, st, *b);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int vbm_launch_pack_residue(const vbm_batch *b, hipStream_t st)
+{
+    const unsigned tiles = (unsigned)((b->nsb + 63) / 64);
+    hipLaunchKernelGGL(k_nonzero_propagate, dim3(tiles), dim3(64), 0, st, *b);
     for (int sm = 0; sm < b->pack_submaps; sm++) {
         int nchunks = b->pack_partvals[sm] < 32 ? b->pack_partvals[sm] : 32;
         if (nchunks < 1) nchunks = 1;
@@ -759,4 +775,10 @@ extern "C" int vbm_launch_pack(const vbm_batch *b, hipStream_t st)
         hipLaunchKernelGGL(k_res_emit, dim3(tiles, (unsigned)nchunks), dim3(64), 0, st, *b, sm, nchunks);
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int vbm_launch_pack(const vbm_batch *b, hipStream_t st)
+{
+    int rc = vbm_launch_pack_head(b, st);
+    return rc ? rc : vbm_launch_pack_residue(b, st);
 }
