@@ -180,7 +180,10 @@ int vbm_encoder_fetch_blob(vbm_encoder *enc, int k, uint8_t *d_packets, int *d_p
  * back to the caller's stream with events, so that the serial few-wavefront kernels of one slice
  * overlap with the wide kernels of the others.  Results do not depend on n.  Default 1
  * (environment VBM_SUB_BATCHES overrides at create); n = 1 launches everything on the caller's
- * stream. */
+ * stream.  In the two-stream form (vbm_analysis_batch2 with two different streams) the slices apply to the
+ * back half only: the first on stream_back, the others on internal streams joined to it.  Measured on MI355X:
+ * every HIP stream beyond four shares a hardware queue with another and costs more than the slices gain, so 1
+ * stays the default. */
 int vbm_encoder_set_sub_batches(vbm_encoder *enc, int n);
 int vbm_encoder_sub_batches(const vbm_encoder *enc);
 

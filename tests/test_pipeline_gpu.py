@@ -129,3 +129,9 @@ def test_stereo_q5_two_stream_form(oracle, cuda):
     overlapping the front half of the next call, no host synchronisation in between; all block types."""
     modes, _ = run_case(oracle, cuda, 2, 44100, 0.5, nstreams=20, seconds=3.0, check_stages=False, two_streams=True)
     assert modes == {0, 1, 2, 3}
+
+
+def test_two_stream_form_with_sub_batches(oracle, cuda):
+    """two-stream form + sub-batches: the back half of a call runs as two slices (caller's back stream and an
+    internal one beside it), joined before the workspace is handed back"""
+    run_case(oracle, cuda, 2, 44100, 0.5, nstreams=150, seconds=0.7, check_stages=False, sub_batches=2, two_streams=True)

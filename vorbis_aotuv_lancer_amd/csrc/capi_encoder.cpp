@@ -537,11 +537,13 @@ extern "C" int vbm_analysis_batch2(vbm_encoder *e, int block_mode, int nsb, cons
     // slices: multiples of 64 stream-blocks
     const int tiles = (nsb + 63) / 64;
     int nsplit = e->nsplit < tiles ? e->nsplit : tiles;
-    if (nsplit < 1 || two) nsplit = 1;   // the two-stream form already overlaps consecutive calls
+    if (nsplit < 1) nsplit = 1;
+    const int nback = nsplit;             // two-stream form: the sub-batches apply to the back half only
+    if (two) nsplit = 1;
 
     int W = b.W;
     int rc = 0;
-    const size_t ev_need = (size_t)2 * (kFront + (size_t)nsplit * kBack);
+    const size_t ev_need = (size_t)2 * (kFront + (size_t)(nsplit > nback ? nsplit : nback) * kBack);
     const bool prof = e->profiling && e->prof_calls < e->prof_max_calls && e->events_used + ev_need <= e->events.size();
     // STAGE(k, q, launch): run `launch` on stream q, bracketed by a (begin, end) event pair when profiling
 #define RUN(x) do { rc = (x); if (rc) { g_vbm_err = std::string("launch failed: ") + #x; return VBM_EHIP; } } while (0)
@@ -566,18 +568,8 @@ extern "C" int vbm_analysis_batch2(vbm_encoder *e, int block_mode, int nsb, cons
                                                vbm_setup_device_ptrs(e->H)->window[0], b.N, s->blocksizes[0], b.ncb, st)));
     STAGE(2, st, RUN(vbm_launch_transpose_in(&b, st)));
 
-    if (nsplit > 1 && (err = hipEventRecord(e->ev_fork, st)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
-    for (int part = 0; part < nsplit; part++) {
-        const int t0 = (int)((long)tiles * part / nsplit), t1 = (int)((long)tiles * (part + 1) / nsplit);
-        const int sb0 = t0 * 64, sb1 = (t1 * 64 < nsb) ? t1 * 64 : nsb;
-        if (sb1 <= sb0) continue;
-        hipStream_t q = st;
-        vbm_batch v = b;
-        if (nsplit > 1) {
-            q = e->sub[part];
-            v = slice_of(b, sb0, sb1 - sb0);
-            if ((err = hipStreamWaitEvent(q, e->ev_fork, 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
-        }
+    // the stages between the transforms and the hand-over: psychoacoustics, offset_and_mix, block state
+    auto front_stages = [&](vbm_batch &v, hipStream_t q, int part) -> int {
         // loop B: psychoacoustics + floor fit (lane per channel-block).  The tone-mask branch reads only
         // the log spectrum and the prologue's maxima, the noise-mask branch only the MDCT: they run side
         // by side on two streams and meet at _vp_offset_and_mix.
@@ -596,19 +588,18 @@ extern "C" int vbm_analysis_batch2(vbm_encoder *e, int block_mode, int nsb, cons
         }
         if (s->managed) STAGE(6, q, RUN(managed_front(v, q)));
         else STAGE(6, q, { RUN(vbm_launch_mix(&v, q)); RUN(vbm_launch_block_state(&v, q)); });
-        if (two) {   // hand over to the back stream
-            if ((err = hipEventRecord(e->ev_front[w], q)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
-            if ((err = hipStreamWaitEvent(sback, e->ev_front[w], 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
-            q = sback;
-        }
+        return 0;
+    };
+    // floor fit .. packets of stream-blocks [sb0, sb0 + v.nsb)
+    auto back_stages = [&](vbm_batch &v, hipStream_t q, int sb0) -> int {
         if (s->managed) {
             STAGE(10, q, RUN(managed_back(v, d_packets ? d_packets + (size_t)sb0 * e->max_packet_bytes : nullptr, q)));
         } else {
-        STAGE(7, q, RUN(vbm_launch_floor_fit(&v, q)));
-        // loop C: floor encode, couple/quantise, residue + packet assembly
-        STAGE(8, q, RUN(vbm_launch_floor_encode(&v, q)));
-        STAGE(9, q, RUN(vbm_launch_couple_quantize(&v, q)));
-        STAGE(10, q, RUN(vbm_launch_pack(&v, q)));
+            STAGE(7, q, RUN(vbm_launch_floor_fit(&v, q)));
+            // loop C: floor encode, couple/quantise, residue + packet assembly
+            STAGE(8, q, RUN(vbm_launch_floor_encode(&v, q)));
+            STAGE(9, q, RUN(vbm_launch_couple_quantize(&v, q)));
+            STAGE(10, q, RUN(vbm_launch_pack(&v, q)));
         }
         STAGE(11, q, {
             if (d_packets && !s->managed)   // word-major tiles -> [nsb][max_packet_bytes] bytes (little-endian words)
@@ -621,14 +612,51 @@ extern "C" int vbm_analysis_batch2(vbm_encoder *e, int block_mode, int nsb, cons
                     return vbm_set_hip_error(err, "hipMemcpyAsync(packet_bytes)");
             }
         });
-        if (nsplit > 1) {
-            if ((err = hipEventRecord(e->ev_join[part], q)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
-            if ((err = hipStreamWaitEvent(st, e->ev_join[part], 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
-        }
-    }
+        return 0;
+    };
+
     if (two) {
+        // front half of the whole batch on the caller's front stream; the back half as `nback` tile-aligned
+        // slices, the first on the caller's back stream and the others on internal streams beside it (their
+        // few-wavefront serial kernels then overlap each other's wide ones), joined back before ev_back
+        vbm_batch v = b;
+        if ((rc = front_stages(v, st, 0))) return rc;
+        if ((err = hipEventRecord(e->ev_front[w], st)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
+        for (int part = 0; part < nback; part++) {
+            const int t0 = (int)((long)tiles * part / nback), t1 = (int)((long)tiles * (part + 1) / nback);
+            const int sb0 = t0 * 64, sb1 = (t1 * 64 < nsb) ? t1 * 64 : nsb;
+            if (sb1 <= sb0) continue;
+            hipStream_t qb = part ? e->sub[part] : sback;
+            if ((err = hipStreamWaitEvent(qb, e->ev_front[w], 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
+            vbm_batch vs = nback > 1 ? slice_of(b, sb0, sb1 - sb0) : b;
+            if ((rc = back_stages(vs, qb, sb0))) return rc;
+            if (part) {
+                if ((err = hipEventRecord(e->ev_join[part], qb)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
+                if ((err = hipStreamWaitEvent(sback, e->ev_join[part], 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
+            }
+        }
         if ((err = hipEventRecord(e->ev_back[w], sback)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
         e->back_pending[w] = true;
+    } else {
+        if (nsplit > 1 && (err = hipEventRecord(e->ev_fork, st)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
+        for (int part = 0; part < nsplit; part++) {
+            const int t0 = (int)((long)tiles * part / nsplit), t1 = (int)((long)tiles * (part + 1) / nsplit);
+            const int sb0 = t0 * 64, sb1 = (t1 * 64 < nsb) ? t1 * 64 : nsb;
+            if (sb1 <= sb0) continue;
+            hipStream_t q = st;
+            vbm_batch v = b;
+            if (nsplit > 1) {
+                q = e->sub[part];
+                v = slice_of(b, sb0, sb1 - sb0);
+                if ((err = hipStreamWaitEvent(q, e->ev_fork, 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
+            }
+            if ((rc = front_stages(v, q, part))) return rc;
+            if ((rc = back_stages(v, q, sb0))) return rc;
+            if (nsplit > 1) {
+                if ((err = hipEventRecord(e->ev_join[part], q)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
+                if ((err = hipStreamWaitEvent(st, e->ev_join[part], 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
+            }
+        }
     }
     if (prof) e->prof_calls++;
 #undef STAGE
