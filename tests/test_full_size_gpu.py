@@ -1,5 +1,5 @@
 """BASELINE configs[2] size on the device: 16384 stereo q5 streams through the front end and the per-block
-path.  Size-independent properties: 16 distinct signals are dealt round-robin over the 16384 streams, so
+path, and configs[4]: 8192 streams of 48 kHz 5.1 q8 (long + short blocks).  Size-independent properties: 16 distinct signals are dealt round-robin over the 16384 streams, so
 every stream must produce exactly the packets of the first stream that carries its signal (any lane / tile /
 batch-position dependence would break this), and those 16 are compared with the oracle."""
 import numpy as np
@@ -12,10 +12,12 @@ from tests.signals import synth_signal
 pytestmark = pytest.mark.gpu
 
 
-def test_16384_streams_from_pcm(oracle, cuda):
+@pytest.mark.parametrize("S,K,ch,rate,q,nchunks", [
+    (16384, 16, 2, 44100, 0.5, 12),      # BASELINE configs[2]
+    (8192, 8, 6, 48000, 0.8, 9),         # BASELINE configs[4]: 5.1, block switching
+])
+def test_full_size_from_pcm(oracle, cuda, S, K, ch, rate, q, nchunks):
     import vorbis_aotuv_lancer_amd as v
-    S, K, ch, rate, q = 16384, 16, 2, 44100, 0.5
-    nchunks = 12
     sigs = [synth_signal(ch, rate, nchunks * 1024, seed=900 + k, level=1.0 if k % 5 else 0.02) for k in range(K)]
     base = torch.from_numpy(np.stack(sigs)).to(cuda)                       # [K, ch, n]
     setup = v.Setup(ch, rate, q)
@@ -46,6 +48,8 @@ def test_16384_streams_from_pcm(oracle, cuda):
                 if p >= 0:
                     first[k].append(bytes(packets[p, :int(nbytes[p])].cpu().numpy()))
     assert nblocks >= S * (nchunks - 3)
+    if ch == 6:
+        assert nblocks > S * nchunks            # short blocks occurred
     osetup = orc.Setup(oracle, ch, rate, q)
     for k in range(K):
         st = orc.Stream(osetup)
