@@ -456,8 +456,7 @@ __global__ void k_floor_encode(vbm_batch b)
     int i, j;
 
     if (!b.post_valid[lane]) {
-        for (i = 0; i < n; i++) T(ilogmask, i) = 0;
-        b.nonzero[lane] = 0;
+        b.nonzero[lane] = 0;    // k_floor_render zero-fills ilogmask
         return;
     }
 
@@ -506,54 +505,80 @@ __global__ void k_floor_encode(vbm_batch b)
         }
     }
 
-    // render the quantised floor exactly as the decoder will (lib/floor1.c:944-967)
-    {
-        int hx = 0;
-        int lx = 0;
-        int ly = T(post, 0) * info->mult;
-
-        for (j = 1; j < posts; j++) {
-            int current = look->forward_index[j];
-            int pc = T(post, current);
-            int hy = pc & 0x7fff;
-            if (hy == pc) {
-                hy *= info->mult;
-                hx = info->postlist[current];
-
-                // render_line0(n, lx, hx, ly, hy, ilogmask)
-                {
-                    int dy = hy - ly;
-                    int adx = hx - lx;
-                    int ady = abs(dy);
-                    int base = dy / adx;
-                    int sy = (dy < 0 ? base - 1 : base + 1);
-                    int x = lx;
-                    int y = ly;
-                    int err = 0;
-                    int nn = n;
-
-                    ady -= abs(base * adx);
-                    if (nn > hx) nn = hx;
-                    if (x < nn) T(ilogmask, x) = y;
-                    while (++x < nn) {
-                        err = err + ady;
-                        if (err >= adx) {
-                            err -= adx;
-                            y += sy;
-                        } else {
-                            y += base;
-                        }
-                        T(ilogmask, x) = y;
-                    }
-                }
-
-                lx = hx;
-                ly = hy;
-            }
-        }
-        for (j = hx; j < n; j++) T(ilogmask, j) = ly;
-    }
     b.nonzero[lane] = 1;
+    (void)n; (void)ilogmask; (void)j;
+}
+
+// The quantised floor rendered exactly as the decoder will (lib/floor1.c:944-967, render_line0 :397-424),
+// sliced over the bins: slice blockIdx.y draws bins [r0, r1) of every channel-block.  A line that starts
+// before the slice is entered at x = r0 with the state its Bresenham walk has there: after k steps the
+// walk has taken floor(k * ady / adx) of the long steps and carries err = (k * ady) mod adx.
+__global__ void k_floor_render(vbm_batch b, int nchunks)
+{
+    const int lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= b.ncb) return;
+    const size_t tb = (size_t)(lane >> 6) * b.slab_words + (lane & 63);
+    const vbm_setup *s = b.setup;
+    const int c = lane % b.ch;
+    const vbm_map *map = &s->map[b.W];
+    const vbm_floor *look = &s->floor[map->floorsubmap[map->chmuxlist[c]]];
+    const int posts = look->posts, mult = look->mult;
+    const int n = b.n;
+    const int r0 = (int)((long)n * blockIdx.y / nchunks), r1 = (int)((long)n * (blockIdx.y + 1) / nchunks);
+    const int *post = b.postT;
+    int *ilogmask = b.iworkT;
+    const int *__restrict__ forward_index = look->forward_index, *__restrict__ postlist = look->postlist;
+
+    if (!b.post_valid[lane]) {
+        for (int i = r0; i < r1; i++) T(ilogmask, i) = 0;
+        return;
+    }
+    int hx = 0, lx = 0;
+    int ly = T(post, 0) * mult;
+    for (int j = 1; j < posts && lx < r1; j++) {
+        const int current = forward_index[j];
+        const int pc = T(post, current);
+        int hy = pc & 0x7fff;
+        if (hy == pc) {
+            hy *= mult;
+            hx = postlist[current];
+            int nn = n;
+            if (nn > hx) nn = hx;            // the line covers [lx, nn)
+            if (nn > r0 && lx < r1) {
+                const int dy = hy - ly;
+                const int adx = hx - lx;
+                const int base = dy / adx;
+                const int sy = (dy < 0 ? base - 1 : base + 1);
+                const int ady = abs(dy) - abs(base * adx);
+                int x = lx, y = ly, err = 0;
+                if (x < r0) {                // enter at r0
+                    const int k = r0 - lx;
+                    const int t = k * ady;   // < 2^31: k < 4096, ady < adx <= 4096
+                    const int q = t / adx;
+                    err = t - q * adx;
+                    y = ly + k * base + q * (sy - base);
+                    x = r0;
+                }
+                const int xe = nn < r1 ? nn : r1;
+                if (x < xe) T(ilogmask, x) = y;
+                while (++x < xe) {
+                    err = err + ady;
+                    if (err >= adx) {
+                        err -= adx;
+                        y += sy;
+                    } else {
+                        y += base;
+                    }
+                    T(ilogmask, x) = y;
+                }
+            }
+            lx = hx;
+            ly = hy;
+        }
+    }
+    // past the last drawn post (lib/floor1.c:966): the walk above may have stopped early (lx >= r1), in which
+    // case hx >= r1 and nothing is left to fill here
+    for (int j2 = (hx > r0 ? hx : r0); j2 < r1; j2++) T(ilogmask, j2) = ly;
 }
 
 }  // namespace
@@ -582,5 +607,7 @@ extern "C" int vbm_launch_floor_interp(const vbm_batch *b, hipStream_t st)
 extern "C" int vbm_launch_floor_encode(const vbm_batch *b, hipStream_t st)
 {
     hipLaunchKernelGGL(k_floor_encode, grid_for(b->ncb), dim3(64), 0, st, *b);
+    const int nchunks = b->n >= 1024 ? 8 : b->n >= 256 ? 4 : 2;
+    hipLaunchKernelGGL(k_floor_render, dim3((unsigned)((b->ncb + 63) / 64), (unsigned)nchunks), dim3(64), 0, st, *b, nchunks);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
