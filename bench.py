@@ -205,6 +205,13 @@ def main():
             fe.write(chunks[k])
             out = None
             rounds = 0
+            if not trace and os.environ.get("VBM_BENCH_SINGLE_ROUNDS", "0") != "1":
+                # all rounds of the write in one call: a round runs beside the long-block batch of the round before
+                # it (vbm_frontend_encode_rounds), everything joined at the end
+                info, pk_, nb_, counts = fe.encode_rounds(min_rounds=MAX_ROUNDS, max_rounds=16, headroom=HOP, device=dev)
+                round_count[0] += len(counts)
+                round_count[1] += len(info)
+                return (pk_, nb_) if len(info) else None
             while True:
                 info, pk_, nb_ = fe.encode_round(dev)
                 if trace:

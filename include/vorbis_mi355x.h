@@ -159,6 +159,18 @@ int vbm_analysis_batch2(vbm_encoder *enc, int block_mode, int nsb, const int *st
  * the grouped order: d_packets[k][max_packet_bytes], d_packet_bytes[k]. */
 int vbm_analysis_round(vbm_encoder *enc, const int *counts, const int *stream_ids, const uint8_t *wflags,
                        const float *d_pcm, uint8_t *d_packets, int *d_packet_bytes, void *stream);
+/* Rounds with a deferred join.  vbm_analysis_round_begin enqueues a round like vbm_analysis_round but does not
+ * make `stream` wait for its batches; a later round only waits for those batches of the round before it that
+ * its own streams were part of (the blocks of a stream stay in order), so the handful of short blocks of one
+ * round runs beside the long-block batch of the previous one.  Outputs are complete on `stream` after
+ * vbm_analysis_round_join.  Buffers handed to a round (d_pcm, outputs) may be reused once `stream` has passed
+ * vbm_analysis_round_wait_workspace before the round after the next, or a join.  (Reference: the application
+ * loop of examples/encoder_example.c:211-235 run for many streams at once; the packets do not depend on how the
+ * rounds are scheduled.) */
+int vbm_analysis_round_begin(vbm_encoder *enc, const int *counts, const int *stream_ids, const uint8_t *wflags,
+                             const float *d_pcm, uint8_t *d_packets, int *d_packet_bytes, void *stream);
+int vbm_analysis_round_join(vbm_encoder *enc, void *stream);
+int vbm_analysis_round_wait_workspace(vbm_encoder *enc, void *stream);
 /* Stage intermediates of the LAST batch as block-major rows ([channel-block][rows]) for parity
  * tests: "mdct_raw" "logfft" "logmdct" "noise" "tone" "logmask" "mdct" "epeak" "npeak" "post"
  * "floor_out" "residue", and the vectors "local_ampmax" "global_ampmax" "post_valid" "nonzero"
@@ -241,6 +253,15 @@ int vbm_frontend_max_buffered(const vbm_frontend *fe);
 int vbm_frontend_capacity(const vbm_frontend *fe);
 int vbm_frontend_encode_round(vbm_frontend *fe, uint8_t *d_packets, int *d_packet_bytes,
                               vbm_packet_info *info, int *nblocks, void *stream);
+/* Up to max_rounds rounds in one call (deferred joins: vbm_analysis_round_begin), results complete on `stream`
+ * when the call's work has run: packets / lengths / infos of all rounds, compact, in round order;
+ * round_blocks[r] = blocks of round r, *nrounds = rounds that produced blocks.  Rounds stop when one produces
+ * nothing, when fewer than `nstreams` of the cap_blocks output slots are left, or — after min_rounds — as
+ * soon as every stream could take `headroom` more samples with its buffer at most half full.  Same packets
+ * as any other schedule of vbm_frontend_encode_round calls. */
+int vbm_frontend_encode_rounds(vbm_frontend *fe, int min_rounds, int max_rounds, int headroom,
+                               uint8_t *d_packets, int *d_packet_bytes, vbm_packet_info *info, int cap_blocks,
+                               int *round_blocks, int *nrounds, void *stream);
 
 /* ---- stream wrapper, host only ------------------------------------------------
  * vbm_header_packets = vorbis_analysis_headerout (reference lib/info.c:636-717): the identification,

@@ -28,9 +28,26 @@ def split_dump(d):
     return out
 
 
-def drain(fe, sink, max_rounds=None):
+def collect(sink, info, packets, nbytes):
+    packets = packets.cpu().numpy()
+    nbytes = nbytes.cpu().numpy()
+    for k, pi in enumerate(info):
+        assert nbytes[k] >= 0, "packet buffer overflow"
+        sink[int(pi["stream"])].append(((int(pi["lW"]), int(pi["W"]), int(pi["nW"]), int(pi["block_mode"]),
+                                         int(pi["eos"]), int(pi["granulepos"]), int(pi["packetno"])),
+                                        bytes(packets[k, :nbytes[k]])))
+
+
+def drain(fe, sink, max_rounds=None, multi=False):
     """rounds until no stream has a block (or, with max_rounds, until that many rounds ran and no buffer
-    is more than half full); sink[stream] collects (info fields, packet bytes)"""
+    is more than half full); sink[stream] collects (info fields, packet bytes).  multi: through
+    vbm_frontend_encode_rounds (several rounds per call, joined at the end)"""
+    if multi:
+        while True:
+            info, packets, nbytes, counts = fe.encode_rounds(min_rounds=max_rounds or 64, max_rounds=4 if max_rounds is None else 16)
+            collect(sink, info, packets, nbytes)
+            if not counts or max_rounds is not None:
+                return
     rounds = 0
     while True:
         if max_rounds is not None and rounds >= max_rounds and fe.max_buffered + 1024 <= fe.capacity // 2:
@@ -87,7 +104,7 @@ def test_frontend_reproduces_reference_packet_dump(oracle, cuda, ch, rate, q, se
 
 
 def frontend_vs_oracle(oracle, cuda, ch, rate, q, NS, seconds, need_modes=(0, 1, 2, 3), max_rounds=None, bitrate=None,
-                       sigs=None):
+                       sigs=None, multi=False):
     import vorbis_aotuv_lancer_amd as v
     nsamp = int(seconds * rate) // 1024 * 1024
     if sigs is None:
@@ -113,7 +130,7 @@ def frontend_vs_oracle(oracle, cuda, ch, rate, q, NS, seconds, need_modes=(0, 1,
     allp = torch.from_numpy(np.stack(sigs)).to(cuda)
     for at in range(0, nsamp, 1024):
         fe.write(allp[:, :, at:at + 1024].contiguous())
-        drain(fe, got, max_rounds)
+        drain(fe, got, max_rounds, multi)
     # vorbis_analysis_wrote(vd, 0) fits its end-of-stream LPC to what the buffer holds at that moment
     # (lib/block.c:531-541), so, like the reference application loop, drain before finishing
     drain(fe, got)
@@ -130,6 +147,17 @@ def frontend_vs_oracle(oracle, cuda, ch, rate, q, NS, seconds, need_modes=(0, 1,
 
 def test_frontend_many_streams_match_oracle(oracle, cuda):
     frontend_vs_oracle(oracle, cuda, 2, 44100, 0.5, NS=70, seconds=1.6)
+
+
+@pytest.mark.parametrize("max_rounds", [None, 2])
+def test_frontend_multi_round_calls_match_oracle(oracle, cuda, max_rounds):
+    """vbm_frontend_encode_rounds: rounds with deferred joins (a round beside the long-block batch of the round
+    before, streams changing block type from round to round) — drained completely, and two rounds per write"""
+    frontend_vs_oracle(oracle, cuda, 2, 44100, 0.5, NS=200, seconds=1.6, multi=True, max_rounds=max_rounds)
+
+
+def test_frontend_multi_round_managed(oracle, cuda):
+    frontend_vs_oracle(oracle, cuda, 2, 44100, None, NS=5, seconds=2.0, bitrate=128000, multi=True)
 
 
 def test_frontend_output_does_not_depend_on_round_policy(oracle, cuda):

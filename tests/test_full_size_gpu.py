@@ -12,11 +12,12 @@ from tests.signals import synth_signal
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("S,K,ch,rate,q,nchunks", [
-    (16384, 16, 2, 44100, 0.5, 12),      # BASELINE configs[2]
-    (8192, 8, 6, 48000, 0.8, 9),         # BASELINE configs[4]: 5.1, block switching
+@pytest.mark.parametrize("S,K,ch,rate,q,nchunks,multi", [
+    (16384, 16, 2, 44100, 0.5, 12, False),     # BASELINE configs[2]
+    (16384, 16, 2, 44100, 0.5, 12, True),      # the same through vbm_frontend_encode_rounds (deferred joins, big batch held)
+    (8192, 8, 6, 48000, 0.8, 9, False),        # BASELINE configs[4]: 5.1, block switching
 ])
-def test_full_size_from_pcm(oracle, cuda, S, K, ch, rate, q, nchunks):
+def test_full_size_from_pcm(oracle, cuda, S, K, ch, rate, q, nchunks, multi):
     import vorbis_aotuv_lancer_amd as v
     sigs = [synth_signal(ch, rate, nchunks * 1024, seed=900 + k, level=1.0 if k % 5 else 0.02) for k in range(K)]
     base = torch.from_numpy(np.stack(sigs)).to(cuda)                       # [K, ch, n]
@@ -28,10 +29,22 @@ def test_full_size_from_pcm(oracle, cuda, S, K, ch, rate, q, nchunks):
     for c in range(nchunks):
         chunk = base[:, :, c * 1024:(c + 1) * 1024].repeat(S // K, 1, 1).contiguous()   # stream s carries signal s % K
         fe.write(chunk)
+        pending = []
         while True:
-            info, packets, nbytes = fe.encode_round()
-            if len(info) == 0:
-                break
+            if multi:
+                if not pending:
+                    info_all, packets_all, nbytes_all, counts = fe.encode_rounds(min_rounds=64, max_rounds=4)
+                    at = 0
+                    for cnt in counts:
+                        pending.append((info_all[at:at + cnt].copy(), packets_all[at:at + cnt], nbytes_all[at:at + cnt]))
+                        at += cnt
+                    if not pending:
+                        break
+                info, packets, nbytes = pending.pop(0)
+            else:
+                info, packets, nbytes = fe.encode_round()
+                if len(info) == 0:
+                    break
             nblocks += len(info)
             # compare on the device: every packet against the packet of stream (s % K) of the same round
             stream = torch.from_numpy(np.ascontiguousarray(info["stream"])).to(cuda).long()

@@ -66,6 +66,12 @@ SIGNATURES = {
     "vbm_frontend_max_buffered": (C.c_int, [C.c_void_p]),
     "vbm_frontend_capacity": (C.c_int, [C.c_void_p]),
     "vbm_frontend_encode_round": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]),
+    "vbm_frontend_encode_rounds": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p]),
+    "vbm_analysis_round_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p]),
+    "vbm_analysis_round_join": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vbm_analysis_round_wait_workspace": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vbm_header_packets": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_void_p, C.c_long, C.POINTER(C.c_long)]),
     "vbm_ogg_stream_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "vbm_ogg_stream_destroy": (None, [C.c_void_p]),

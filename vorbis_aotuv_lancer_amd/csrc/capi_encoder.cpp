@@ -10,6 +10,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <algorithm>
+#include <thread>
 #include <vector>
 
 #include "vorbis_mi355x.h"
@@ -64,6 +66,13 @@ struct vbm_encoder {
     struct span { int stage; size_t begin, end; };
     std::vector<span> spans;
     int prof_calls = 0, prof_max_calls = 0;
+    // rounds with a deferred join (vbm_analysis_round_begin / _join): completion of every block type's batch
+    // per workspace, and the batch each stream was part of in the previous round
+    hipEvent_t ev_done[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
+    bool done_pending[2][4] = {{false, false, false, false}, {false, false, false, false}};
+    std::vector<signed char> round_type;   // [S] block type of the stream's batch in the last round, -1 none
+    bool round_big[4] = {false, false, false, false};   // ... and whether that batch ran on the big-batch stream
+    int round_w = -1;                      // workspace of that round
     // the tone-mask branch of a slice runs on its own stream beside the noise-mask branch
     bool overlap_branches = true;
     std::vector<hipStream_t> aux;
@@ -78,6 +87,7 @@ static const int kFront = 3;                       // stages launched on the who
 static const int kBack = kNumStages - kFront;      // stages launched per slice
 
 static int round64(int x) { return (x + 63) & ~63; }
+static const int kBigBatch = 1024;   // stream-blocks from which a round's batch counts as big (own stream; front end holds its streams)
 
 template <typename T>
 static int dalloc(vbm_encoder *e, T **p, size_t count, bool zero = true)
@@ -103,6 +113,9 @@ extern "C" void vbm_encoder_destroy(vbm_encoder *e)
     for (hipEvent_t ev : e->ev_aux_fork) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : e->ev_aux_join) (void)hipEventDestroy(ev);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    for (int i = 0; i < 2; i++)
+        for (int m = 0; m < 4; m++)
+            if (e->ev_done[i][m]) (void)hipEventDestroy(e->ev_done[i][m]);
     for (int i = 0; i < 2; i++) {
         if (e->ev_front[i]) (void)hipEventDestroy(e->ev_front[i]);
         if (e->ev_back[i]) (void)hipEventDestroy(e->ev_back[i]);
@@ -296,6 +309,13 @@ extern "C" int vbm_encoder_create(vbm_encoder **out, vbm_setup_handle *setup, in
         vbm_encoder_destroy(e);
         return VBM_EHIP;
     }
+    for (int i = 0; i < 2; i++)
+        for (int m = 0; m < 4; m++)
+            if (hipEventCreateWithFlags(&e->ev_done[i][m], hipEventDisableTiming) != hipSuccess) {
+                vbm_encoder_destroy(e);
+                return VBM_EHIP;
+            }
+    e->round_type.assign(nstreams, -1);
     {
         const char *env = getenv("VBM_SUB_BATCHES");
         int rc2 = vbm_encoder_set_sub_batches(e, env ? atoi(env) : 1);
@@ -364,6 +384,7 @@ int vbm_encoder_reset_streams_dev(vbm_encoder *e, const int *d_ids, int n, hipSt
 {
     const vbm_setup *s = e->hs;
     const long long fill = s->managed ? (long long)((double)s->bi_reservoir_bits * s->bi_reservoir_bias) : 0;
+    if (vbm_analysis_round_join(e, q)) return VBM_EHIP;
     return vbm_launch_reset_streams(&e->bw[0].st, d_ids, n, fill, q) ? VBM_EHIP : VBM_OK;
 }
 
@@ -503,6 +524,11 @@ extern "C" int vbm_analysis_batch2(vbm_encoder *e, int block_mode, int nsb, cons
     hipStream_t sback = (hipStream_t)stream_back;
     const bool two = (sback != st);
     hipError_t err;
+    {   // rounds begun with a deferred join are completed first: their streams may be in this batch
+        int rcj = vbm_analysis_round_join(e, stream);
+        if (rcj) return rcj;
+        e->round_w = -1;
+    }
     const int w = e->next;
     e->next ^= 1;
     e->cur = w;
@@ -670,8 +696,13 @@ extern "C" int vbm_analysis_batch2(vbm_encoder *e, int block_mode, int nsb, cons
 // The four batches are independent (different streams), so each runs on its own internal HIP stream
 // on a tile-aligned slice of the workspace; a handful of short blocks then costs the round no more
 // than the big long-block batch it runs beside.  Outputs are compact: packet k of the grouped order.
-extern "C" int vbm_analysis_round(vbm_encoder *e, const int *counts, const int *stream_ids, const uint8_t *wflags,
-                                  const float *d_pcm, uint8_t *d_packets, int *d_packet_bytes, void *stream)
+extern "C" int vbm_analysis_round_join(vbm_encoder *e, void *stream);
+
+// `defer`: the batches are not joined back to `stream`; vbm_analysis_round_join does that.  A deferred round only
+// waits for the batches of the previous round that its own streams were part of (a stream's blocks stay in
+// order), so the few short blocks of one round can run beside the long-block batch of the round before.
+static int analysis_round_impl(vbm_encoder *e, const int *counts, const int *stream_ids, const uint8_t *wflags,
+                               const float *d_pcm, uint8_t *d_packets, int *d_packet_bytes, void *stream, bool defer)
 {
     if (!e || !counts || !stream_ids || !wflags || !d_pcm) return VBM_EINVAL;
     if (((uintptr_t)d_pcm & 15) || ((uintptr_t)d_packets & 3)) return VBM_EINVAL;
@@ -699,6 +730,25 @@ extern "C" int vbm_analysis_round(vbm_encoder *e, const int *counts, const int *
     if (e->back_pending[w]) {
         if ((err = hipStreamWaitEvent(st, e->ev_back[w], 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
         e->back_pending[w] = false;
+    }
+    // the round before the previous one used this workspace: all of it has to be done
+    for (int m = 0; m < 4; m++)
+        if (e->done_pending[w][m]) {
+            if ((err = hipStreamWaitEvent(st, e->ev_done[w][m], 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
+            e->done_pending[w][m] = false;
+        }
+    // which batches of the previous round do the streams of each batch of this round come from?
+    bool dep[4][4] = {};
+    if (e->round_w == (w ^ 1))
+        for (int m = 0; m < 4; m++)
+            for (int i = 0; i < counts[m]; i++) {
+                const int t = e->round_type[stream_ids[off[m] + i]];
+                if (t >= 0) dep[m][t] = true;
+            }
+    if (getenv("VBM_ROUND_DEBUG")) {
+        fprintf(stderr, "round w=%d defer=%d counts=[%d %d %d %d] dep:", w, (int)defer, counts[0], counts[1], counts[2], counts[3]);
+        for (int m = 0; m < 4; m++) fprintf(stderr, " %d<-[%d%d%d%d]", m, dep[m][0], dep[m][1], dep[m][2], dep[m][3]);
+        fprintf(stderr, "\n");
     }
     // ids / flags in the padded lane layout, through the pinned staging (always uploaded: the layout changes
     // from round to round)
@@ -728,7 +778,7 @@ extern "C" int vbm_analysis_round(vbm_encoder *e, const int *counts, const int *
     // streams with disjoint CU masks (hipExtStreamCreateWithCUMask) — both slower: the single-wavefront
     // kernels of the small batches run several times slower beside the wide kernels of the big batch, so
     // their chains are better run next to each other than one after another.
-    while ((int)e->sub.size() < 4) {
+    while ((int)e->sub.size() < 5) {      // one per block type + one for a big batch (see below)
         hipStream_t q;
         hipEvent_t ev;
         if (hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess ||
@@ -740,11 +790,22 @@ extern "C" int vbm_analysis_round(vbm_encoder *e, const int *counts, const int *
     for (int a = 0; a < 4; a++)
         for (int c = a + 1; c < 4; c++)
             if (counts[order[c]] > counts[order[a]]) { int t_ = order[a]; order[a] = order[c]; order[c] = t_; }
-    for (int rank = 0; rank < 4; rank++) {
-        const int m = order[rank];
-        if (!counts[m]) continue;
-        hipStream_t q = e->sub[m];
+    // The ~40 launches of a block type's pipeline cost the host more than the kernels of a small batch cost the
+    // device, and the four types are independent: every type is enqueued by its own host thread (the largest
+    // batch on the calling thread), each on its own HIP stream.
+    int dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    auto enqueue_type = [&](const int m) -> int {
+        hipError_t err;
+        int rc = 0;
+        // a big batch gets a stream of its own: the few blocks of its type in the next round must not queue behind it
+        const bool bigb = counts[m] >= kBigBatch;
+        hipStream_t q = bigb ? e->sub[4] : e->sub[m];
         if ((err = hipStreamWaitEvent(q, e->ev_fork, 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
+        for (int t = 0; t < 4; t++)
+            if ((t != m || bigb != e->round_big[t]) && dep[m][t] && e->done_pending[w ^ 1][t] &&
+                (err = hipStreamWaitEvent(q, e->ev_done[w ^ 1][t], 0)) != hipSuccess)
+                return vbm_set_hip_error(err, "hipStreamWaitEvent");
         vbm_batch full;
         configure(e, full, m, counts[m], d_pcm, w);
         vbm_batch v = slice_of(full, pad[m], counts[m]);
@@ -778,10 +839,80 @@ extern "C" int vbm_analysis_round(vbm_encoder *e, const int *counts, const int *
         if (d_packet_bytes &&
             (err = hipMemcpyAsync(d_packet_bytes + off[m], v.packet_bytes, v.nsb * sizeof(int), hipMemcpyDeviceToDevice, q)) != hipSuccess)
             return vbm_set_hip_error(err, "hipMemcpyAsync(packet_bytes)");
-        if ((err = hipEventRecord(e->ev_join[m], q)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
-        if ((err = hipStreamWaitEvent(st, e->ev_join[m], 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
+        if ((err = hipEventRecord(e->ev_done[w][m], q)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
+        return VBM_OK;
+    };
+    int rcs[4] = {0, 0, 0, 0};
+    std::string msgs[4];
+    std::thread workers[4];
+    const bool threaded = !getenv("VBM_ROUND_SINGLE_THREAD");
+    for (int rank = 3; rank >= 0; rank--) {      // smallest first: their threads start while the big one is enqueued here
+        const int m = order[rank];
+        if (!counts[m]) continue;
+        e->done_pending[w][m] = true;
+        if (rank == 0 || !threaded) {
+            rcs[m] = enqueue_type(m);
+            if (rcs[m]) msgs[m] = g_vbm_err;
+        } else {
+            workers[m] = std::thread([&, m]() {
+                (void)hipSetDevice(dev_id);
+                rcs[m] = enqueue_type(m);
+                if (rcs[m]) msgs[m] = g_vbm_err;
+            });
+        }
     }
+    for (int m = 0; m < 4; m++)
+        if (workers[m].joinable()) workers[m].join();
+    for (int m = 0; m < 4; m++)
+        if (rcs[m]) { g_vbm_err = msgs[m]; return rcs[m]; }
 #undef RUN
+    for (int m = 0; m < 4; m++) e->round_big[m] = counts[m] >= kBigBatch;
+    // remember which batch every stream of this round belongs to
+    if (e->round_w >= 0) std::fill(e->round_type.begin(), e->round_type.end(), (signed char)-1);
+    for (int m = 0; m < 4; m++)
+        for (int i = 0; i < counts[m]; i++) e->round_type[stream_ids[off[m] + i]] = (signed char)m;
+    e->round_w = w;
+    return defer ? VBM_OK : vbm_analysis_round_join(e, stream);
+}
+
+extern "C" int vbm_analysis_round(vbm_encoder *e, const int *counts, const int *stream_ids, const uint8_t *wflags,
+                                  const float *d_pcm, uint8_t *d_packets, int *d_packet_bytes, void *stream)
+{
+    return analysis_round_impl(e, counts, stream_ids, wflags, d_pcm, d_packets, d_packet_bytes, stream, false);
+}
+
+extern "C" int vbm_analysis_round_begin(vbm_encoder *e, const int *counts, const int *stream_ids, const uint8_t *wflags,
+                                        const float *d_pcm, uint8_t *d_packets, int *d_packet_bytes, void *stream)
+{
+    return analysis_round_impl(e, counts, stream_ids, wflags, d_pcm, d_packets, d_packet_bytes, stream, true);
+}
+
+// `stream` waits for every batch of the rounds begun so far
+extern "C" int vbm_analysis_round_join(vbm_encoder *e, void *stream)
+{
+    if (!e) return VBM_EINVAL;
+    for (int w = 0; w < 2; w++)
+        for (int m = 0; m < 4; m++)
+            if (e->done_pending[w][m]) {
+                hipError_t err = hipStreamWaitEvent((hipStream_t)stream, e->ev_done[w][m], 0);
+                if (err != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
+                e->done_pending[w][m] = false;
+            }
+    return VBM_OK;
+}
+
+// `stream` waits until the workspace the next round will use is free (buffers handed to that round may then
+// be rewritten on `stream`)
+extern "C" int vbm_analysis_round_wait_workspace(vbm_encoder *e, void *stream)
+{
+    if (!e) return VBM_EINVAL;
+    const int w = e->next;
+    for (int m = 0; m < 4; m++)
+        if (e->done_pending[w][m]) {
+            hipError_t err = hipStreamWaitEvent((hipStream_t)stream, e->ev_done[w][m], 0);
+            if (err != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
+            e->done_pending[w][m] = false;
+        }
     return VBM_OK;
 }
 

@@ -32,7 +32,10 @@ struct vbm_frontend {
     int *d_ids = nullptr, *d_begin = nullptr;             // [S] per-round lists, grouped by block type
     int *h_ids = nullptr, *h_begin = nullptr;             // pinned
     uint8_t *h_flags = nullptr;
-    float *d_blocks = nullptr;            // [S][ch][blocksizes[1]] block-major batches of one round
+    uint8_t *d_hold = nullptr, *h_hold = nullptr;         // [S] streams left alone in the later rounds of a multi-round call
+    bool hold_active = false;
+    float *d_blocks = nullptr;            // [2][S][ch][blocksizes[1]] block-major batches of one round (two rounds in flight)
+    int blocks_turn = 0;
     // host mirrors (bounds checking and skipping rounds that cannot produce a block)
     std::vector<int> pcm_current, W, started, ended;
     bool dirty = false;                   // samples arrived since the envelope was last evaluated
@@ -58,6 +61,7 @@ extern "C" void vbm_frontend_destroy(vbm_frontend *fe)
     if (fe->h_ids) (void)hipHostFree(fe->h_ids);
     if (fe->h_begin) (void)hipHostFree(fe->h_begin);
     if (fe->h_flags) (void)hipHostFree(fe->h_flags);
+    if (fe->h_hold) (void)hipHostFree(fe->h_hold);
     delete fe;
 }
 
@@ -100,7 +104,13 @@ extern "C" int vbm_frontend_create(vbm_frontend **out, vbm_encoder *enc)
     A(f.ve_spec, float, SC * VBM_FE_CHUNK * 64);
     A(fe->d_dec, vbm_fe_decision, S);
     A(fe->d_ids, int, S); A(fe->d_begin, int, S);
-    A(fe->d_blocks, float, SC * bs1);
+    A(fe->d_blocks, float, 2 * SC * bs1);
+    A(fe->d_hold, uint8_t, (size_t)S);
+    if (hipHostMalloc((void **)&fe->h_hold, (size_t)S, hipHostMallocDefault) != hipSuccess) {
+        vbm_frontend_destroy(fe);
+        g_vbm_err = "hipHostMalloc(hold mask) failed";
+        return VBM_EHIP;
+    }
 #undef A
     if (hipHostMalloc((void **)&fe->h_dec, S * sizeof(vbm_fe_decision), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void **)&fe->h_ids, S * sizeof(int), hipHostMallocDefault) != hipSuccess ||
@@ -301,8 +311,10 @@ extern "C" int vbm_frontend_finish(vbm_frontend *fe, const int *stream_ids, int 
     return VBM_OK;
 }
 
-extern "C" int vbm_frontend_encode_round(vbm_frontend *fe, uint8_t *d_packets, int *d_packet_bytes,
-                                         vbm_packet_info *info, int *nblocks, void *stream)
+static vbm_encoder *vbm_frontend_encoder(vbm_frontend *fe) { return fe->enc; }
+
+static int round_impl(vbm_frontend *fe, uint8_t *d_packets, int *d_packet_bytes, vbm_packet_info *info, int *nblocks,
+                      void *stream, bool defer)
 {
     if (!fe || !nblocks || !info) return VBM_EINVAL;
     *nblocks = 0;
@@ -341,7 +353,7 @@ extern "C" int vbm_frontend_encode_round(vbm_frontend *fe, uint8_t *d_packets, i
         fe->pending_steps = 0;
     }
 
-    if (vbm_fe_launch_decide(&fe->f, ds, fe->d_dec, st)) return VBM_EHIP;
+    if (vbm_fe_launch_decide(&fe->f, ds, fe->d_dec, fe->hold_active ? fe->d_hold : nullptr, st)) return VBM_EHIP;
     if ((err = hipMemcpyAsync(fe->h_dec, fe->d_dec, S * sizeof(vbm_fe_decision), hipMemcpyDeviceToHost, st)) != hipSuccess)
         return vbm_set_hip_error(err, "hipMemcpyAsync(decisions)");
     if ((err = hipStreamSynchronize(st)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamSynchronize");
@@ -378,18 +390,85 @@ extern "C" int vbm_frontend_encode_round(vbm_frontend *fe, uint8_t *d_packets, i
         (err = hipMemcpyAsync(fe->d_begin, fe->h_begin, total * sizeof(int), hipMemcpyHostToDevice, st)) != hipSuccess)
         return vbm_set_hip_error(err, "hipMemcpyAsync(round lists)");
 
+    // the block buffer of this turn was read by the round before the previous one
+    {
+        int rc = vbm_analysis_round_wait_workspace(fe->enc, stream);
+        if (rc) return rc;
+    }
+    float *round_blocks = fe->d_blocks + (size_t)fe->blocks_turn * S * ch * bs1;
+    fe->blocks_turn ^= 1;
     for (int m = 0; m < 4; m++) {
         if (!count[m]) continue;
         const int N = (m >> 1) ? bs1 : bs0;
-        float *blocks = fe->d_blocks + (size_t)offset[m] * ch * bs1;
+        float *blocks = round_blocks + (size_t)offset[m] * ch * bs1;
         if (vbm_fe_launch_gather(&fe->f, fe->d_ids + offset[m], fe->d_begin + offset[m], count[m], N, blocks, st))
             return VBM_EHIP;
     }
     {
-        int rc = vbm_analysis_round(fe->enc, count, fe->h_ids, fe->h_flags, fe->d_blocks, d_packets, d_packet_bytes, stream);
+        int rc = defer ? vbm_analysis_round_begin(fe->enc, count, fe->h_ids, fe->h_flags, round_blocks, d_packets, d_packet_bytes, stream)
+                       : vbm_analysis_round(fe->enc, count, fe->h_ids, fe->h_flags, round_blocks, d_packets, d_packet_bytes, stream);
         if (rc) return rc;
     }
     if (vbm_fe_launch_shift(&fe->f, fe->d_dec, st)) return VBM_EHIP;
     *nblocks = total;
     return VBM_OK;
+}
+
+extern "C" int vbm_frontend_encode_round(vbm_frontend *fe, uint8_t *d_packets, int *d_packet_bytes,
+                                         vbm_packet_info *info, int *nblocks, void *stream)
+{
+    return round_impl(fe, d_packets, d_packet_bytes, info, nblocks, stream, false);
+}
+
+// Several rounds in one call, joined at the end: a round only waits for the batches of the round before it that
+// its own streams were in, so the short blocks of the streams that need many rounds run beside the long-block
+// batch of the previous round.  Rounds stop when none produced a block, after max_rounds, when fewer than
+// nstreams output slots are left, or — past min_rounds — once every stream could take `headroom` more samples
+// without its buffer passing half full.  Outputs are compact over the rounds, in round order.
+extern "C" int vbm_frontend_encode_rounds(vbm_frontend *fe, int min_rounds, int max_rounds, int headroom,
+                                          uint8_t *d_packets, int *d_packet_bytes, vbm_packet_info *info,
+                                          int cap_blocks, int *round_blocks, int *nrounds, void *stream)
+{
+    if (!fe || !info || !nrounds || max_rounds < 1 || min_rounds < 0 || cap_blocks < 0) return VBM_EINVAL;
+    *nrounds = 0;
+    const int maxb = vbm_encoder_max_packet_bytes(fe->enc);
+    int done = 0, rc = VBM_OK;
+    for (int r = 0; r < max_rounds; r++) {
+        if (cap_blocks - done < fe->S) break;
+        if (r >= min_rounds && vbm_frontend_max_buffered(fe) + headroom <= vbm_frontend_capacity(fe) / 2) break;
+        int n = 0;
+        rc = round_impl(fe, d_packets ? d_packets + (size_t)done * maxb : nullptr, d_packet_bytes ? d_packet_bytes + done : nullptr,
+                        info + done, &n, stream, true);
+        if (rc || n == 0) break;
+        if (round_blocks) round_blocks[r] = n;
+        if (r == 0 && max_rounds > 1) {
+            // The streams of a big batch are left alone for the rest of this call: a block of theirs in a later
+            // round would make that round's batch wait for the big one (a stream's blocks stay in order), and
+            // with it every stream that shares the batch.  They get their next block in the next call.
+            int cnt[4] = {0, 0, 0, 0};
+            for (int k = 0; k < n; k++) cnt[info[done + k].block_mode & 3]++;
+            int big = 0;
+            for (int m = 1; m < 4; m++)
+                if (cnt[m] > cnt[big]) big = m;
+            if (cnt[big] >= 1024) {
+                memset(fe->h_hold, 0, fe->S);
+                // ... unless they are behind: a stream whose buffer is filling up keeps its place in every round
+                const int half = vbm_frontend_capacity(fe) / 2;
+                for (int k = 0; k < n; k++) {
+                    const int sid = info[done + k].stream;
+                    if ((info[done + k].block_mode & 3) == big && fe->pcm_current[sid] + headroom <= half) fe->h_hold[sid] = 1;
+                }
+                if (hipMemcpyAsync(fe->d_hold, fe->h_hold, fe->S, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) {
+                    rc = VBM_EHIP;
+                    break;
+                }
+                fe->hold_active = true;
+            }
+        }
+        done += n;
+        *nrounds = r + 1;
+    }
+    fe->hold_active = false;
+    int rj = vbm_analysis_round_join(vbm_frontend_encoder(fe), stream);
+    return rc ? rc : rj;
 }

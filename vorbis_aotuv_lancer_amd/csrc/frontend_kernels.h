@@ -11,7 +11,8 @@ int vbm_fe_launch_restart(const vbm_fe_state *f, const int *d_ids, int n, int lo
 int vbm_fe_launch_extrapolate(const vbm_fe_state *f, const int *d_ids, int nids, int mode, int long_n, hipStream_t st);
 int vbm_fe_launch_ve_range(const vbm_fe_state *f, hipStream_t st);
 int vbm_fe_launch_ve_filter(const vbm_fe_state *f, const vbm_setup *d_setup, int t0, hipStream_t st);
-int vbm_fe_launch_decide(const vbm_fe_state *f, const vbm_setup *d_setup, vbm_fe_decision *d_out, hipStream_t st);
+int vbm_fe_launch_decide(const vbm_fe_state *f, const vbm_setup *d_setup, vbm_fe_decision *d_out, const uint8_t *d_hold,
+                         hipStream_t st);
 int vbm_fe_launch_gather(const vbm_fe_state *f, const int *d_ids, const int *d_begin, int count, int N, float *d_dst,
                          hipStream_t st);
 int vbm_fe_launch_shift(const vbm_fe_state *f, const vbm_fe_decision *d_dec, hipStream_t st);

@@ -400,7 +400,9 @@ __global__ __launch_bounds__(64) void k_fe_ve_filter(vbm_fe_state f, const vbm_s
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ void k_fe_decide(vbm_fe_state f, const vbm_setup *__restrict__ setup, vbm_fe_decision *__restrict__ out)
+// hold (may be NULL): streams marked there are left alone in this round (no block, no state change)
+__global__ void k_fe_decide(vbm_fe_state f, const vbm_setup *__restrict__ setup, vbm_fe_decision *__restrict__ out,
+                            const uint8_t *__restrict__ hold)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= f.S) return;
@@ -416,7 +418,7 @@ __global__ void k_fe_decide(vbm_fe_state f, const vbm_setup *__restrict__ setup,
     const int bsW = W ? bs1 : bs0;
     const int beginW = centerW - bsW / 2;
 
-    if (!f.preextrapolate[s] || eofflag == -1) {
+    if (!f.preextrapolate[s] || eofflag == -1 || (hold && hold[s])) {
         out[s] = d;
         return;
     }
@@ -631,9 +633,10 @@ extern "C" int vbm_fe_launch_ve_filter(const vbm_fe_state *f, const vbm_setup *d
     return CHECK_LAUNCH();
 }
 
-extern "C" int vbm_fe_launch_decide(const vbm_fe_state *f, const vbm_setup *d_setup, vbm_fe_decision *d_out, hipStream_t st)
+extern "C" int vbm_fe_launch_decide(const vbm_fe_state *f, const vbm_setup *d_setup, vbm_fe_decision *d_out,
+                                    const uint8_t *d_hold, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_fe_decide, dim3((unsigned)((f->S + 63) / 64)), dim3(64), 0, st, *f, d_setup, d_out);
+    hipLaunchKernelGGL(k_fe_decide, dim3((unsigned)((f->S + 63) / 64)), dim3(64), 0, st, *f, d_setup, d_out, d_hold);
     return CHECK_LAUNCH();
 }
 

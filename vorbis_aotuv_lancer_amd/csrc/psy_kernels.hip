@@ -794,8 +794,10 @@ struct mod3 {
 
 // QF: also leave the floor fit's input word of every bin (floor_kernels.hip: dBquant(logmask) | test << 15) in
 // the LDS tile qtile[bin - i0][lane]; the kernel writes the tile out as block-major rows.
-template <int SEL, bool MANAGED, bool QF>
-__device__ __forceinline__ void mix_body(const vbm_batch &b, const int nchunks, const int lane, uint16_t (*qtile)[66])
+// M0 (impulse blocks: one slice, M3 walks tempmdct with dependent read-modify-writes): the lane's tempmdct
+// column lives in LDS (tl[row * 64]) for the duration of the kernel.
+template <int SEL, bool MANAGED, bool QF, bool M0>
+__device__ __forceinline__ void mix_body(const vbm_batch &b, const int nchunks, const int lane, uint16_t (*qtile)[66], float *tl)
 {
     constexpr bool BUF = (!MANAGED || SEL == 2);   // mp->mdctbuf_flag of set_m3p when the rate is high (lib/psy.c:4165-4173)
     const size_t tb = TB(b, lane);
@@ -809,7 +811,9 @@ __device__ __forceinline__ void mix_body(const vbm_batch &b, const int nchunks, 
     float *lastmdct = b.st.mblock + (size_t)(col >> 6) * b.st.slab_words + (col & 63);   // element i at [i*64]
     float *tempmdct = b.st.tblock + (size_t)(col >> 6) * b.st.slab_words + (col & 63);
 #define LAST(i) lastmdct[(size_t)(i) * 64]
-#define TEMP(i) tempmdct[(size_t)(i) * 64]
+#define TEMP(i) (*(M0 ? &tl[(i) * 64] : &tempmdct[(size_t)(i) * 64]))
+    if (M0)
+        for (int r = 0; r < 256; r++) tl[r * 64] = tempmdct[(size_t)r * 64];
     const float *noise = b.noiseT, *tone = b.toneT;
     float *logmask = b.logmaskT, *mdct = b.mdctT, *logmdct = b.logmdctT, *npeak = b.npeakT;
     const int offset_select = SEL;
@@ -1057,6 +1061,8 @@ __device__ __forceinline__ void mix_body(const vbm_batch &b, const int nchunks, 
             break;
         }
     }
+    if (M0 && BUF)
+        for (int r = 0; r < 256; r++) tempmdct[(size_t)r * 64] = tl[r * 64];
 #undef LAST
 #undef TEMP
 }
@@ -1066,15 +1072,16 @@ __device__ __forceinline__ void mix_body(const vbm_batch &b, const int nchunks, 
 // bin range into `nchunks` slices (blockIdx.y) for block modes 1..3 and uses one slice for mode 0.
 // QF (slices of at most 64 bins): the slice's floor-fit words go out as block-major rows qf_bm[block][n]
 // (what k_floor_prep would compute from logmask and logmdct in a pass of its own).
-template <int SEL, bool MANAGED, bool QF>
+template <int SEL, bool MANAGED, bool QF, bool M0>
 __global__ void k_mix(vbm_batch b, int nchunks)
 {
+    extern __shared__ float mix_temp[];   // M0: [256][64] tempmdct columns of this wavefront
     __shared__ uint16_t qtile[QF ? 64 : 1][66];
     __shared__ uint8_t colact[64];
     const int lane = blockIdx.x * blockDim.x + threadIdx.x;
     // managed bitrate: the hi / lo rate passes run only for channels whose first fit exists (lib/mapping0.c:1097)
     const bool active = lane < b.ncb && !(MANAGED && SEL != 1 && !b.post_valid_blob[(size_t)(VBM_PACKETBLOBS / 2) * b.L + lane]);
-    if (active) mix_body<SEL, MANAGED, QF>(b, nchunks, lane, qtile);
+    if (active) mix_body<SEL, MANAGED, QF, M0>(b, nchunks, lane, qtile, mix_temp + threadIdx.x);
     if (QF) {
         colact[threadIdx.x] = active ? 1 : 0;
         __syncthreads();
@@ -1135,12 +1142,36 @@ extern "C" int vbm_launch_tonemask(const vbm_batch *b, hipStream_t st)
     hipLaunchKernelGGL(k_tm_apply, dim3(tiles, (unsigned)nchunks), dim3(64), 0, st, *b, nchunks);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
+static const size_t kMixTempBytes = (size_t)256 * 64 * sizeof(float);   // impulse blocks: tempmdct columns in LDS
+
+// the impulse-block variants take 64 KB of dynamic LDS on top of their static tiles: above the default limit
+template <typename K>
+static void allow_big_lds(K kernel)
+{
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)kMixTempBytes);
+}
+static void mix_m0_setup()
+{
+    static bool done = false;
+    if (done) return;
+    allow_big_lds(k_mix<1, false, false, true>);
+    allow_big_lds(k_mix<1, true, false, true>);
+    allow_big_lds(k_mix<2, true, false, true>);
+    allow_big_lds(k_mix<0, true, false, true>);
+    done = true;
+}
+
 extern "C" int vbm_launch_mix(const vbm_batch *b, hipStream_t st)
 {
     const int nchunks = (b->block_mode == 0) ? 1 : bin_chunks(b);
     const dim3 grid((unsigned)((b->ncb + 63) / 64), (unsigned)nchunks);
-    if (b->mix_makes_qf) hipLaunchKernelGGL((k_mix<1, false, true>), grid, dim3(64), 0, st, *b, nchunks);
-    else hipLaunchKernelGGL((k_mix<1, false, false>), grid, dim3(64), 0, st, *b, nchunks);
+    if (b->block_mode == 0) {
+        mix_m0_setup();
+        hipLaunchKernelGGL((k_mix<1, false, false, true>), grid, dim3(64), kMixTempBytes, st, *b, nchunks);
+    }
+    else if (b->mix_makes_qf) hipLaunchKernelGGL((k_mix<1, false, true, false>), grid, dim3(64), 0, st, *b, nchunks);
+    else hipLaunchKernelGGL((k_mix<1, false, false, false>), grid, dim3(64), 0, st, *b, nchunks);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 // slices of at most 64 bins fit the 64 x 64 tile k_mix writes the floor-fit words through
@@ -1153,14 +1184,19 @@ extern "C" int vbm_launch_mix_managed(const vbm_batch *b, int offset_select, hip
 {
     const int nchunks = (b->block_mode == 0) ? 1 : bin_chunks(b);
     const dim3 grid((unsigned)((b->ncb + 63) / 64), (unsigned)nchunks);
-    if (b->mix_makes_qf) {
-        if (offset_select == 1) hipLaunchKernelGGL((k_mix<1, true, true>), grid, dim3(64), 0, st, *b, nchunks);
-        else if (offset_select == 2) hipLaunchKernelGGL((k_mix<2, true, true>), grid, dim3(64), 0, st, *b, nchunks);
-        else hipLaunchKernelGGL((k_mix<0, true, true>), grid, dim3(64), 0, st, *b, nchunks);
+    if (b->block_mode == 0) {
+        mix_m0_setup();
+        if (offset_select == 1) hipLaunchKernelGGL((k_mix<1, true, false, true>), grid, dim3(64), kMixTempBytes, st, *b, nchunks);
+        else if (offset_select == 2) hipLaunchKernelGGL((k_mix<2, true, false, true>), grid, dim3(64), kMixTempBytes, st, *b, nchunks);
+        else hipLaunchKernelGGL((k_mix<0, true, false, true>), grid, dim3(64), kMixTempBytes, st, *b, nchunks);
+    } else if (b->mix_makes_qf) {
+        if (offset_select == 1) hipLaunchKernelGGL((k_mix<1, true, true, false>), grid, dim3(64), 0, st, *b, nchunks);
+        else if (offset_select == 2) hipLaunchKernelGGL((k_mix<2, true, true, false>), grid, dim3(64), 0, st, *b, nchunks);
+        else hipLaunchKernelGGL((k_mix<0, true, true, false>), grid, dim3(64), 0, st, *b, nchunks);
     } else {
-        if (offset_select == 1) hipLaunchKernelGGL((k_mix<1, true, false>), grid, dim3(64), 0, st, *b, nchunks);
-        else if (offset_select == 2) hipLaunchKernelGGL((k_mix<2, true, false>), grid, dim3(64), 0, st, *b, nchunks);
-        else hipLaunchKernelGGL((k_mix<0, true, false>), grid, dim3(64), 0, st, *b, nchunks);
+        if (offset_select == 1) hipLaunchKernelGGL((k_mix<1, true, false, false>), grid, dim3(64), 0, st, *b, nchunks);
+        else if (offset_select == 2) hipLaunchKernelGGL((k_mix<2, true, false, false>), grid, dim3(64), 0, st, *b, nchunks);
+        else hipLaunchKernelGGL((k_mix<0, true, false, false>), grid, dim3(64), 0, st, *b, nchunks);
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -222,6 +222,29 @@ class FrontEnd:
         k = n.value
         return self._info_view[:k], packets[:k], nbytes[:k]
 
+    def encode_rounds(self, min_rounds=1, max_rounds=8, headroom=1024, device=None):
+        """Up to max_rounds blockout rounds in one call (vbm_frontend_encode_rounds: a round runs beside the
+        long-block batch of the round before it; everything is joined at the end).  Returns (info records,
+        packets uint8 [n, max_bytes], nbytes int32 [n], blocks per round) over all rounds, in round order."""
+        dev = device or torch.device("cuda", torch.cuda.current_device())
+        S = self.enc.nstreams
+        cap = S * max_rounds
+        if getattr(self, "_multi_cap", 0) < cap:
+            self._multi_info = (PacketInfo * cap)()
+            self._multi_view = np.ctypeslib.as_array(self._multi_info)
+            self._multi_cap = cap
+        packets = torch.empty((cap, self.enc.max_packet_bytes), dtype=torch.uint8, device=dev)
+        nbytes = torch.empty((cap,), dtype=torch.int32, device=dev)
+        per_round = (C.c_int * max_rounds)()
+        nr = C.c_int()
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(lib.vbm_frontend_encode_rounds(self._h, min_rounds, max_rounds, headroom, packets.data_ptr(), nbytes.data_ptr(),
+                                             self._multi_info, cap, per_round, C.byref(nr), st),
+              "vbm_frontend_encode_rounds")
+        counts = [per_round[r] for r in range(nr.value)]
+        k = sum(counts)
+        return self._multi_view[:k], packets[:k], nbytes[:k], counts
+
     def close(self):
         if self._h:
             lib.vbm_frontend_destroy(self._h)
