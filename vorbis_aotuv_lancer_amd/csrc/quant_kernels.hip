@@ -517,12 +517,119 @@ struct fast_consts {
     nn_consts nn;
 };
 
+
+// noise_normalize (lib/psy.c:4732-4854) for one 32-bin partition held by the 32 lanes of a half-wave, lane j =
+// bin j (the caller has established start < n).  What the source leaves order-bound is kept in its order:
+//  * acc, the float sum of the small values in bin order: a 32-step loop over the lanes' values;
+//  * ssort's partial selection sort (lib/psy.c:4709-4726, ties included: its swaps decide which of two equal
+//    magnitudes comes first): position p of the sort[] array lives in lane p, every step is a 5-step
+//    (key, position) maximum over the half-wave followed by the swap of two lanes' entries;
+//  * the promotions: acc only falls, so the promoted elements are the first P of the sorted order.
+// `slot`: 32 ints of LDS scratch of this half-wave (the inverse permutation goes through it).
+__device__ __forceinline__ void nn_wave(const nn_consts &p, const int limit, const float r, float &q, const float f, float &res,
+                                        const bool has_flags, const int flag, const float nepeak, const int i, const int n,
+                                        const int j, const int base, int *slot, int &out)
+{
+    int start = (p.normal_p ? p.normal_start - i : n);
+    if ((start > n) || ((double)nepeak < -0.5)) start = n;
+    const bool inr = j < n;
+    bool member = false;
+    float vem = 0.f;
+    if (inr && j < start) {
+        if (!has_flags) {
+            out = (int)rint((double)res);
+        } else if (flag != 1) {
+            const float ve = (float)sqrt((double)(q / f));
+            if (r < 0) { out = (int)-rint((double)ve); res = -ve; }
+            else { out = (int)rint((double)ve); res = ve; }
+        }
+    } else if (inr) {
+        if (has_flags) {
+            if (flag != 1) {
+                float ve = q / f;
+                if (ve < .25f && j >= limit - i) {
+                    member = true;
+                    vem = ve;
+                    if (r < 0) res = (float)-sqrt((double)ve);
+                    else res = (float)sqrt((double)ve);
+                } else {
+                    ve = (float)sqrt((double)ve);
+                    int o;
+                    if (r < 0) { o = (int)-rint((double)ve); res = -ve; }
+                    else { o = (int)rint((double)ve); res = ve; }
+                    out = o;
+                    q = o * o * f;
+                }
+            }
+        } else {
+            const float ve = res * res;
+            if (ve < .25f) {
+                member = true;
+                vem = ve;
+            } else {
+                const int o = (int)rint((double)res);
+                out = o;
+                q = o * o * f;
+            }
+        }
+    }
+    const unsigned mask = (unsigned)(__ballot(member) >> base);
+    const int count = __popc(mask);
+    if (count == 0) return;                              // uniform over the half-wave
+    float acc = 0.f;
+    for (int t = 0; t < FP; t++) {
+        const float v = __shfl(vem, base + t);
+        if ((mask >> t) & 1u) acc += v;
+    }
+    acc += acc * nepeak * nepeak;
+    int iacc = ((int)acc) + 1;
+    if (iacc > n) iacc = n;
+    const int bthresh = count < iacc ? count : iacc;
+    // lane p < count: entry p of sort[] = the p-th member in bin order
+    int e = 0;
+    {
+        unsigned m = mask;
+        for (int t = 0; t < j && m; t++) m &= m - 1;     // drop the j lowest set bits
+        e = m ? __ffs(m) - 1 : 0;
+    }
+    float key = __shfl(q, base + e);
+    const bool live = j < count;
+    for (int a = 0; a < bthresh; a++) {
+        float bk = (live && j >= a) ? key : -3.0e38f;
+        int bp = (live && j >= a) ? j : 64;
+#pragma unroll
+        for (int sft = 16; sft >= 1; sft >>= 1) {
+            const float ok = __shfl_xor(bk, sft);
+            const int op = __shfl_xor(bp, sft);
+            // the scan `if (q[sort[large]] < q[sort[bb]]) large = bb` keeps the earliest of equal maxima
+            if (ok > bk || (ok == bk && op < bp)) { bk = ok; bp = op; }
+        }
+        const int large = bp;                            // uniform
+        const int eA = __shfl(e, base + a), eL = __shfl(e, base + large);
+        const float kA = __shfl(key, base + a), kL = __shfl(key, base + large);
+        if (j == a) { e = eL; key = kL; }
+        else if (j == large) { e = eA; key = kA; }
+    }
+    int P = 0;
+    {
+        float a2 = acc;
+        while (P < count && (double)a2 >= p.normal_thresh) { a2 -= 1.f; P++; }
+    }
+    if (live) slot[e] = j;                               // element e sits at position j of the sorted order
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    if (member) {
+        const int pos = slot[j];
+        if (pos < P) { out = (int)vbm_unitnorm(r); q = f; }
+        else { out = 0; q = 0.f; }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 struct fast_lds {
     float in_md[2][FP][FPC + 1], in_ep[2][FP][FPC + 1];
     int in_iw[2][FP][FPC + 1];
-    // serial fallback of noise_normalize: per half-wave arrays
-    float r[FPC][FP], q[FPC][FP], f[FPC][FP], res[FPC][FP];
-    int flag[FPC][FP], out[FPC][FP];
+    int out[FPC][FP];   // nn_wave's scratch (inverse permutation of the partial sort), one row per half-wave
 };
 
 // per-channel part of a partition for this lane's bin (lib/psy.c:4952-4991)
@@ -579,15 +686,7 @@ __device__ __forceinline__ void fast_channel(const fast_consts &c, fast_lds &L, 
     if (start >= jn) {
         out = (int)rint((double)res);
     } else {
-        (void)base;
-        L.r[g][j] = raw; L.q[g][j] = quant; L.f[g][j] = floor; L.res[g][j] = res; L.out[g][j] = 0;
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        if (j == 0)
-            noise_normalize(&c.nn, c.limit, L.r[g], L.q[g], L.f[g], L.res[g], nullptr, 0.f, nepeak, i, jn, L.out[g], 1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        quant = L.q[g][j]; res = L.res[g][j]; out = L.out[g][j];
+        nn_wave(c.nn, c.limit, raw, quant, floor, res, false, 0, nepeak, i, jn, j, base, L.out[g], out);
     }
 }
 
@@ -743,16 +842,7 @@ __global__ __launch_bounds__(FP * FPC) void k_couple_fast(vbm_batch b)
                             }
                         }
                     } else {
-                        L.r[g][j] = reM; L.q[g][j] = qeM; L.f[g][j] = floorM; L.res[g][j] = resM; L.flag[g][j] = fM;
-                        L.out[g][j] = oM;
-                        __builtin_amdgcn_wave_barrier();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                        if (j == 0)
-                            noise_normalize(&c.nn, c.limit, L.r[g], L.q[g], L.f[g], L.res[g], L.flag[g], 0.f, npM, i, jn,
-                                            L.out[g], 1);
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                        __builtin_amdgcn_wave_barrier();
-                        oM = L.out[g][j];
+                        nn_wave(c.nn, c.limit, reM, qeM, floorM, resM, true, fM, npM, i, jn, j, base, L.out[g], oM);
                     }
                 }
             }
