@@ -255,7 +255,8 @@ extern "C" int vbm_encoder_create(vbm_encoder **out, vbm_setup_handle *setup, in
         int max_steps = 1;
         for (int i = 0; i < s->modes && i < 2; i++)
             if (s->map[i].coupling_steps > max_steps) max_steps = s->map[i].coupling_steps;
-        const size_t o_pw = stake((size_t)e->max_partvals * e->ch), o_vq = stake((size_t)nmax * e->ch),
+        // (the residue VQ stages its partitions in LDS: no interleaved copy of the residue in HBM any more)
+        const size_t o_pw = stake((size_t)e->max_partvals * e->ch), o_vq = stake(1),
                      o_m6 = stake((size_t)(nmax / 8 + 1) * max_steps);
         int max_stages = 1;
         for (int i = 0; i < s->residues; i++)
