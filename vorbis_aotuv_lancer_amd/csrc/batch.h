@@ -85,6 +85,7 @@ struct vbm_batch {
     int *packet_bits;               // [Ls]  write position while the packet is assembled
     int max_packet_bytes;           // multiple of 4
     // managed bitrate (lib/mapping0.c:1097-1181, :1204): the back half runs once per packetblob
+    int fit_max_posts;              // largest post count of the floors this block type's channels use (host copy)
     int mix_makes_qf;               // k_mix leaves the floor fit's input words (qf_bm) itself: no k_floor_prep pass
     int blobno;                     // blob the floor encode / couple / pack kernels work on (PACKETBLOBS/2 for VBR)
     int *postT_blob;                // [PACKETBLOBS][VIF_POSIT+2][L] in the tile slab: fits of blobs 0, 7, 14 + the interpolated ones

@@ -403,6 +403,12 @@ static void configure(vbm_encoder *e, vbm_batch &b, int block_mode, int nsb, con
     b.Ls = e->Ls;
     b.pcm = d_pcm;
     b.blobno = VBM_PACKETBLOBS / 2;
+    b.fit_max_posts = 2;
+    for (int c = 0; c < e->ch; c++) {
+        const vbm_map &mp = s->map[b.W];
+        const int posts = s->floor[mp.floorsubmap[mp.chmuxlist[c]]].posts;
+        if (posts > b.fit_max_posts) b.fit_max_posts = posts;
+    }
     b.mix_makes_qf = getenv("VBM_SEPARATE_FLOOR_PREP") ? 0 : vbm_mix_can_make_qf(&b);
     {
         // partition slicing of couple/quantise (quant_kernels.hip): allowed when no channel takes part
