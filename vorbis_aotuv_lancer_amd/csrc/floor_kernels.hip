@@ -644,7 +644,8 @@ extern "C" int vbm_launch_floor_interp(const vbm_batch *b, hipStream_t st)
 extern "C" int vbm_launch_floor_encode(const vbm_batch *b, hipStream_t st)
 {
     hipLaunchKernelGGL(k_floor_encode, grid_for(b->ncb), dim3(64), 0, st, *b);
-    const int nchunks = b->n >= 1024 ? 8 : b->n >= 256 ? 4 : 2;
+    int nchunks = b->n >= 1024 ? 8 : b->n >= 256 ? 4 : 2;
+    if (b->ncb <= 1024 && b->n / 16 > nchunks) nchunks = b->n / 16;   // small batch: latency-bound, finer slices
     hipLaunchKernelGGL(k_floor_render, dim3((unsigned)((b->ncb + 63) / 64), (unsigned)nchunks), dim3(64), 0, st, *b, nchunks);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -1106,7 +1106,15 @@ static inline int bin_chunks(const vbm_batch *b)
         big = e ? atoi(e) : 16;
         if (big < 1 || big > 64) big = 16;
     }
-    return b->n >= 1024 ? big : b->n >= 512 ? 8 : b->n >= 256 ? 4 : 2;
+    const int chunks = b->n >= 1024 ? big : b->n >= 512 ? 8 : b->n >= 256 ? 4 : 2;
+    // A small batch (the short rounds of the front end: a few wavefronts on an empty chip) is bound by the
+    // latency of each wavefront's walk over its bins, not by throughput: slices of 8-16 bins instead of 64.
+    if (b->ncb <= 1024) {
+        int fine = b->n / (b->n >= 1024 ? 16 : 8);
+        if (fine > 64) fine = 64;
+        if (fine > chunks) return fine;
+    }
+    return chunks;
 }
 
 extern "C" int vbm_launch_prologue(const vbm_batch *b, hipStream_t st)
