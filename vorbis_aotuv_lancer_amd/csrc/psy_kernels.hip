@@ -671,17 +671,22 @@ __global__ void k_tm_chase(vbm_batch b, int lpw)
     // entry falling out is in memory already), a pop shifts them up.  Memory is only read when a run of
     // pops has used up the register copies: then the next TM_K - 1 levels are fetched together.
 #define TM_K 8
+#ifndef TM_KV
+#define TM_KV 32
+#endif
     int stack = 0, nreg = 0;
     float ra[TM_K];
     int rp[TM_K];
 #pragma unroll
     for (int k = 0; k < TM_K; k++) { ra[k] = 0.f; rp[k] = 0; }
-    for (int i = 0; i < tn; i += 8) {
-        int kv[8];
+    // seeds are read TM_KV at a time: every batch has to wait for the stack stores issued since the last one
+    // (loads and stores retire in order), so fewer, larger batches
+    for (int i = 0; i < tn; i += TM_KV) {
+        int kv[TM_KV];
 #pragma unroll
-        for (int u = 0; u < 8; u++) kv[u] = seedL[(unsigned)((i + u < tn) ? i + u : tn - 1) << 6];
+        for (int u = 0; u < TM_KV; u++) kv[u] = seedL[(unsigned)((i + u < tn) ? i + u : tn - 1) << 6];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
+        for (int u = 0; u < TM_KV; u++) {
             const int ii = i + u;
             if (ii < tn) {
                 const float v = seed_val(kv[u]);
