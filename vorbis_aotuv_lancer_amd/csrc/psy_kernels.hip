@@ -802,7 +802,8 @@ struct mod3 {
 // M0 (impulse blocks: one slice, M3 walks tempmdct with dependent read-modify-writes): the lane's tempmdct
 // column lives in LDS (tl[row * 64]) for the duration of the kernel.
 template <int SEL, bool MANAGED, bool QF, bool M0>
-__device__ __forceinline__ void mix_body(const vbm_batch &b, const int nchunks, const int lane, uint16_t (*qtile)[66], float *tl)
+__device__ __forceinline__ void mix_body(const vbm_batch &b, const int nchunks, const int lane, uint16_t (*qtile)[66], float *tl,
+                                         const int *bfn_lds)
 {
     constexpr bool BUF = (!MANAGED || SEL == 2);   // mp->mdctbuf_flag of set_m3p when the rate is high (lib/psy.c:4165-4173)
     const size_t tb = TB(b, lane);
@@ -859,7 +860,8 @@ __device__ __forceinline__ void mix_body(const vbm_batch &b, const int nchunks, 
         } else if (block_mode) {
             mp3.sw = 0;
         } else if (n == 128 || n == 256) {
-            const int *bfn = (n == 128) ? s->freq_bfn128 : s->freq_bfn256;
+            // impulse blocks: the table sits in LDS (M3 PRE reads it in a dependent double loop)
+            const int *bfn = M0 ? bfn_lds : ((n == 128) ? s->freq_bfn128 : s->freq_bfn256);
             int count;
             if (n == 128) {
                 if (toneatt < 3) count = 2;
@@ -1086,7 +1088,14 @@ __global__ void k_mix(vbm_batch b, int nchunks)
     const int lane = blockIdx.x * blockDim.x + threadIdx.x;
     // managed bitrate: the hi / lo rate passes run only for channels whose first fit exists (lib/mapping0.c:1097)
     const bool active = lane < b.ncb && !(MANAGED && SEL != 1 && !b.post_valid_blob[(size_t)(VBM_PACKETBLOBS / 2) * b.L + lane]);
-    if (active) mix_body<SEL, MANAGED, QF, M0>(b, nchunks, lane, qtile, mix_temp + threadIdx.x);
+    __shared__ int s_bfn[M0 ? 256 : 1];
+    if (M0) {
+        const int *g = (b.n == 128) ? b.setup->freq_bfn128 : b.setup->freq_bfn256;
+        const int cnt = (b.n == 128) ? 128 : 256;
+        for (int t = threadIdx.x; t < cnt; t += 64) s_bfn[t] = g[t];
+        __syncthreads();
+    }
+    if (active) mix_body<SEL, MANAGED, QF, M0>(b, nchunks, lane, qtile, mix_temp + threadIdx.x, s_bfn);
     if (QF) {
         colact[threadIdx.x] = active ? 1 : 0;
         __syncthreads();
