@@ -24,6 +24,8 @@
 extern "C" int vbm_launch_spread_flags(const vbm_batch *b, hipStream_t st);
 vbm_setup_host *vbm_setup_handle_host(vbm_setup_handle *h);
 
+static const int kMaxWS = 4;
+
 struct vbm_encoder {
     vbm_setup_host *H;
     const vbm_setup *hs;     // host view
@@ -36,13 +38,15 @@ struct vbm_encoder {
     // alternate between them, so that vbm_analysis_batch2 can run the second half of call k (floor fit,
     // couple/quantise, packet assembly) on one HIP stream while the first half of call k+1 (transforms,
     // psychoacoustics — everything that touches the carried stream state) runs on another.
-    vbm_batch bw[2];
-    int *d_stream_id[2];
-    uint8_t *d_wflags[2];
+    int nws = 2;             // workspaces in rotation (2: a call's back half beside the next call's front half; more let
+                             // the short rounds of the front end run on while a big batch still holds its workspace)
+    vbm_batch bw[kMaxWS];
+    int *d_stream_id[kMaxWS];
+    uint8_t *d_wflags[kMaxWS];
     int cur = 0;             // workspace of the last call (vbm_encoder_fetch)
     int next = 0;            // workspace of the next call
-    hipEvent_t ev_front[2] = {nullptr, nullptr}, ev_back[2] = {nullptr, nullptr};
-    bool back_pending[2] = {false, false};
+    hipEvent_t ev_front[kMaxWS] = {}, ev_back[kMaxWS] = {};
+    bool back_pending[kMaxWS] = {};
     // last batch (for vbm_encoder_fetch)
     int last_nsb, last_mode;
     // sub-batches: the stages after the transforms run as `nsplit` tile-aligned slices of the batch,
@@ -57,8 +61,8 @@ struct vbm_encoder {
     uint8_t *h_flags[2] = {nullptr, nullptr};
     hipEvent_t ev_stage[2] = {nullptr, nullptr};
     int stage_turn = 0;
-    std::vector<int> last_ids[2];
-    std::vector<uint8_t> last_flags[2];
+    std::vector<int> last_ids[kMaxWS];
+    std::vector<uint8_t> last_flags[kMaxWS];
     // optional per-stage timing (HIP events on the stream each kernel is launched on)
     bool profiling = false;
     std::vector<hipEvent_t> events;   // pool; a (begin, end) pair per recorded stage launch
@@ -68,8 +72,8 @@ struct vbm_encoder {
     int prof_calls = 0, prof_max_calls = 0;
     // rounds with a deferred join (vbm_analysis_round_begin / _join): completion of every block type's batch
     // per workspace, and the batch each stream was part of in the previous round
-    hipEvent_t ev_done[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
-    bool done_pending[2][4] = {{false, false, false, false}, {false, false, false, false}};
+    hipEvent_t ev_done[kMaxWS][4] = {};
+    bool done_pending[kMaxWS][4] = {};
     std::vector<signed char> round_type;   // [S] block type of the stream's batch in the last round, -1 none
     bool round_big[4] = {false, false, false, false};   // ... and whether that batch ran on the big-batch stream
     int round_w = -1;                      // workspace of that round
@@ -113,10 +117,10 @@ extern "C" void vbm_encoder_destroy(vbm_encoder *e)
     for (hipEvent_t ev : e->ev_aux_fork) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : e->ev_aux_join) (void)hipEventDestroy(ev);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < kMaxWS; i++)
         for (int m = 0; m < 4; m++)
             if (e->ev_done[i][m]) (void)hipEventDestroy(e->ev_done[i][m]);
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < kMaxWS; i++) {
         if (e->ev_front[i]) (void)hipEventDestroy(e->ev_front[i]);
         if (e->ev_back[i]) (void)hipEventDestroy(e->ev_back[i]);
     }
@@ -213,7 +217,13 @@ extern "C" int vbm_encoder_create(vbm_encoder **out, vbm_setup_handle *setup, in
         (void)hipMemcpy(b.st.vbi_ampmax, init.data(), nstreams * sizeof(float), hipMemcpyHostToDevice);
     }
   }
-  for (int w = 0; w < 2; w++) {
+  {
+      const char *env = getenv("VBM_WORKSPACES");
+      e->nws = env ? atoi(env) : 2;
+      if (e->nws < 2) e->nws = 2;
+      if (e->nws > kMaxWS) e->nws = kMaxWS;
+  }
+  for (int w = 0; w < e->nws; w++) {
     vbm_batch &b = e->bw[w];
     if (w) {
         memset(&b, 0, sizeof(b));
@@ -291,7 +301,7 @@ extern "C" int vbm_encoder_create(vbm_encoder **out, vbm_setup_handle *setup, in
     b.wflags = e->d_wflags[w];
   }
 #undef A
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < kMaxWS; i++)
         if (hipEventCreateWithFlags(&e->ev_front[i], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&e->ev_back[i], hipEventDisableTiming) != hipSuccess) {
             vbm_encoder_destroy(e);
@@ -310,7 +320,7 @@ extern "C" int vbm_encoder_create(vbm_encoder **out, vbm_setup_handle *setup, in
         vbm_encoder_destroy(e);
         return VBM_EHIP;
     }
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < kMaxWS; i++)
         for (int m = 0; m < 4; m++)
             if (hipEventCreateWithFlags(&e->ev_done[i][m], hipEventDisableTiming) != hipSuccess) {
                 vbm_encoder_destroy(e);
@@ -362,6 +372,7 @@ extern "C" int vbm_encoder_sub_batches(const vbm_encoder *e) { return e ? e->nsp
 // internal accessors for the stream front end (capi_frontend.cpp)
 vbm_setup_host *vbm_encoder_setup_host(vbm_encoder *e) { return e->H; }
 int vbm_encoder_streams(const vbm_encoder *e) { return e->S; }
+int vbm_encoder_workspaces(const vbm_encoder *e) { return e->nws; }
 
 extern "C" int vbm_encoder_max_packet_bytes(const vbm_encoder *e) { return e ? e->max_packet_bytes : VBM_EINVAL; }
 
@@ -537,7 +548,7 @@ extern "C" int vbm_analysis_batch2(vbm_encoder *e, int block_mode, int nsb, cons
         e->round_w = -1;
     }
     const int w = e->next;
-    e->next ^= 1;
+    e->next = (e->next + 1) % e->nws;
     e->cur = w;
     // this workspace was last read by the back half of the call before the previous one
     if (e->back_pending[w]) {
@@ -732,7 +743,7 @@ static int analysis_round_impl(vbm_encoder *e, const int *counts, const int *str
     hipStream_t st = (hipStream_t)stream;
     hipError_t err;
     const int w = e->next;
-    e->next ^= 1;
+    e->next = (e->next + 1) % e->nws;
     e->cur = w;
     if (e->back_pending[w]) {
         if ((err = hipStreamWaitEvent(st, e->ev_back[w], 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
@@ -746,7 +757,8 @@ static int analysis_round_impl(vbm_encoder *e, const int *counts, const int *str
         }
     // which batches of the previous round do the streams of each batch of this round come from?
     bool dep[4][4] = {};
-    if (e->round_w == (w ^ 1))
+    const int prev = (w + e->nws - 1) % e->nws;   // workspace of the round before this one
+    if (e->round_w == prev)
         for (int m = 0; m < 4; m++)
             for (int i = 0; i < counts[m]; i++) {
                 const int t = e->round_type[stream_ids[off[m] + i]];
@@ -810,8 +822,8 @@ static int analysis_round_impl(vbm_encoder *e, const int *counts, const int *str
         hipStream_t q = bigb ? e->sub[4] : e->sub[m];
         if ((err = hipStreamWaitEvent(q, e->ev_fork, 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
         for (int t = 0; t < 4; t++)
-            if ((t != m || bigb != e->round_big[t]) && dep[m][t] && e->done_pending[w ^ 1][t] &&
-                (err = hipStreamWaitEvent(q, e->ev_done[w ^ 1][t], 0)) != hipSuccess)
+            if ((t != m || bigb != e->round_big[t]) && dep[m][t] && e->done_pending[prev][t] &&
+                (err = hipStreamWaitEvent(q, e->ev_done[prev][t], 0)) != hipSuccess)
                 return vbm_set_hip_error(err, "hipStreamWaitEvent");
         vbm_batch full;
         configure(e, full, m, counts[m], d_pcm, w);
@@ -898,7 +910,7 @@ extern "C" int vbm_analysis_round_begin(vbm_encoder *e, const int *counts, const
 extern "C" int vbm_analysis_round_join(vbm_encoder *e, void *stream)
 {
     if (!e) return VBM_EINVAL;
-    for (int w = 0; w < 2; w++)
+    for (int w = 0; w < e->nws; w++)
         for (int m = 0; m < 4; m++)
             if (e->done_pending[w][m]) {
                 hipError_t err = hipStreamWaitEvent((hipStream_t)stream, e->ev_done[w][m], 0);

@@ -19,6 +19,7 @@
 
 vbm_setup_host *vbm_encoder_setup_host(vbm_encoder *e);
 int vbm_encoder_streams(const vbm_encoder *e);
+int vbm_encoder_workspaces(const vbm_encoder *e);
 int vbm_encoder_reset_streams_dev(vbm_encoder *e, const int *d_ids, int n, hipStream_t q);
 
 struct vbm_frontend {
@@ -35,7 +36,7 @@ struct vbm_frontend {
     uint8_t *d_hold = nullptr, *h_hold = nullptr;         // [S] streams left alone in the later rounds of a multi-round call
     bool hold_active = false;
     float *d_blocks = nullptr;            // [2][S][ch][blocksizes[1]] block-major batches of one round (two rounds in flight)
-    int blocks_turn = 0;
+    int blocks_turn = 0, nblocks_bufs = 2;
     // host mirrors (bounds checking and skipping rounds that cannot produce a block)
     std::vector<int> pcm_current, W, started, ended;
     bool dirty = false;                   // samples arrived since the envelope was last evaluated
@@ -104,7 +105,8 @@ extern "C" int vbm_frontend_create(vbm_frontend **out, vbm_encoder *enc)
     A(f.ve_spec, float, SC * VBM_FE_CHUNK * 64);
     A(fe->d_dec, vbm_fe_decision, S);
     A(fe->d_ids, int, S); A(fe->d_begin, int, S);
-    A(fe->d_blocks, float, 2 * SC * bs1);
+    fe->nblocks_bufs = vbm_encoder_workspaces(enc);   // a round's blocks are read until its workspace is handed on
+    A(fe->d_blocks, float, (size_t)fe->nblocks_bufs * SC * bs1);
     A(fe->d_hold, uint8_t, (size_t)S);
     if (hipHostMalloc((void **)&fe->h_hold, (size_t)S, hipHostMallocDefault) != hipSuccess) {
         vbm_frontend_destroy(fe);
@@ -396,7 +398,7 @@ static int round_impl(vbm_frontend *fe, uint8_t *d_packets, int *d_packet_bytes,
         if (rc) return rc;
     }
     float *round_blocks = fe->d_blocks + (size_t)fe->blocks_turn * S * ch * bs1;
-    fe->blocks_turn ^= 1;
+    fe->blocks_turn = (fe->blocks_turn + 1) % fe->nblocks_bufs;
     for (int m = 0; m < 4; m++) {
         if (!count[m]) continue;
         const int N = (m >> 1) ? bs1 : bs0;
