@@ -647,6 +647,7 @@ __global__ void k_tm_stamp(vbm_batch b, int nchunks)
     }
 }
 
+template <int TM_KV>
 __global__ void k_tm_chase(vbm_batch b, int lpw)
 {
     // `lpw` lanes per wavefront: the walk is latency-bound, fewer lanes per wave = more waves in flight
@@ -671,16 +672,14 @@ __global__ void k_tm_chase(vbm_batch b, int lpw)
     // entry falling out is in memory already), a pop shifts them up.  Memory is only read when a run of
     // pops has used up the register copies: then the next TM_K - 1 levels are fetched together.
 #define TM_K 8
-#ifndef TM_KV
-#define TM_KV 32
-#endif
     int stack = 0, nreg = 0;
     float ra[TM_K];
     int rp[TM_K];
 #pragma unroll
     for (int k = 0; k < TM_K; k++) { ra[k] = 0.f; rp[k] = 0; }
     // seeds are read TM_KV at a time: every batch has to wait for the stack stores issued since the last one
-    // (loads and stores retire in order), so fewer, larger batches
+    // (loads and stores retire in order).  32 for small batches (latency is all that counts: 0.37 -> 0.2 ms),
+    // 8 for full ones (fewer registers; beside the other kernels the larger batches were slightly slower)
     for (int i = 0; i < tn; i += TM_KV) {
         int kv[TM_KV];
 #pragma unroll
@@ -1160,7 +1159,8 @@ extern "C" int vbm_launch_tonemask(const vbm_batch *b, hipStream_t st)
         lpw = e ? atoi(e) : 64;
         if (lpw < 1 || lpw > 64) lpw = 64;
     }
-    hipLaunchKernelGGL(k_tm_chase, dim3((unsigned)((b->ncb + lpw - 1) / lpw)), dim3(64), 0, st, *b, lpw);
+    if (b->ncb <= 1024) hipLaunchKernelGGL(k_tm_chase<32>, dim3((unsigned)((b->ncb + lpw - 1) / lpw)), dim3(64), 0, st, *b, lpw);
+    else hipLaunchKernelGGL(k_tm_chase<8>, dim3((unsigned)((b->ncb + lpw - 1) / lpw)), dim3(64), 0, st, *b, lpw);
     hipLaunchKernelGGL(k_tm_apply, dim3(tiles, (unsigned)nchunks), dim3(64), 0, st, *b, nchunks);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
