@@ -248,7 +248,10 @@ int vbm_frontend_write_streams(vbm_frontend *fe, const int *stream_ids, int n, c
 int vbm_frontend_restart_streams(vbm_frontend *fe, const int *stream_ids, int n, void *stream);
 /* Buffer occupancy, for callers that do not drain completely after every write (a stream inside a
  * run of short blocks yields up to 8 blocks per 1024 samples, each in its own round): the most
- * samples any stream holds now, and the occupancy a write may not exceed (VBM_EINVAL beyond it). */
+ * samples any stream holds now, and the occupancy a write may not exceed (VBM_EINVAL beyond it).  The buffer
+ * is 16 long blocks per channel (environment VBM_FE_BUFFER_BLOCKS, 8..64, read at create), 3 of them reserved
+ * for the end-of-stream padding: the slack lets such a stream fall behind and catch up, instead of forcing
+ * extra rounds on every write.  (The reference grows its buffer on demand: lib/block.c:424-430.) */
 int vbm_frontend_max_buffered(const vbm_frontend *fe);
 int vbm_frontend_capacity(const vbm_frontend *fe);
 int vbm_frontend_encode_round(vbm_frontend *fe, uint8_t *d_packets, int *d_packet_bytes,

@@ -52,7 +52,7 @@ def test_frontend_write_errors(cuda):
     assert lib.vbm_frontend_write(fe._h, chunk.data_ptr(), 5000, None) == VBM_EINVAL     # more than two long blocks at once
     # without draining, the buffers fill up: the write that would overrun is refused (lib/block.c:540-541)
     refused = False
-    for _ in range(16):
+    for _ in range(fe.capacity // 1024 + 2):
         rc = lib.vbm_frontend_write(fe._h, chunk.data_ptr(), 1024, None)
         if rc == VBM_EINVAL:
             refused = True

@@ -83,7 +83,15 @@ extern "C" int vbm_frontend_create(vbm_frontend **out, vbm_encoder *enc)
     f.ch = ch;
     // room for the carried window (< 2 long blocks), one write of up to 2 long blocks and the three
     // long blocks of end-of-stream padding (lib/block.c:527-529)
-    f.cap = (long)bs1 * 8;
+    // PCM buffer per channel, in long blocks.  3 are reserved for the end-of-stream padding (lib/block.c:531);
+    // what is left is slack: a stream inside a run of short blocks falls behind the others and catches up
+    // later, and the more it may fall behind, the fewer rounds a write forces (VBM_FE_BUFFER_BLOCKS, 8..64;
+    // measured at 16384 streams, one 1024-sample write per step: 8 -> 11.9 ms, 12 -> 10.1, 16 -> 9.5, 24 -> 9.5).
+    int cap_blocks = 16;
+    if (const char *env = getenv("VBM_FE_BUFFER_BLOCKS")) cap_blocks = atoi(env);
+    if (cap_blocks < 8) cap_blocks = 8;
+    if (cap_blocks > 64) cap_blocks = 64;
+    f.cap = (long)bs1 * cap_blocks;
     f.plane = (long)S * ch * f.cap;
     f.marks = (int)(f.cap / 64) + 8;
     int rc = 0;
