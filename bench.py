@@ -28,6 +28,8 @@ if "--from-pcm" in sys.argv:
     # the four block types of a blockout round run on four internal HIP streams next to the caller's; the ROCm
     # runtime folds HIP streams onto 4 hardware queues by default, which makes two of them share one
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    # lazy joins (the back half of a write's long-block batch beside the next write) need a third workspace
+    os.environ.setdefault("VBM_WORKSPACES", "4")
 
 import numpy as np
 import torch
@@ -35,6 +37,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+LAZY_JOIN = os.environ.get("VBM_BENCH_LAZY_JOIN", "1") != "0"   # --from-pcm: vbm_frontend_encode_rounds_lazy
+kept = []
 STREAMS_PER_GPU = int(os.environ.get("VBM_BENCH_STREAMS", "16384"))
 CHANNELS = 2
 RATE = 44100
@@ -208,9 +212,13 @@ def main():
             if not trace and os.environ.get("VBM_BENCH_SINGLE_ROUNDS", "0") != "1":
                 # all rounds of the write in one call: a round runs beside the long-block batch of the round before
                 # it (vbm_frontend_encode_rounds), everything joined at the end
-                info, pk_, nb_, counts = fe.encode_rounds(min_rounds=MAX_ROUNDS, max_rounds=16, headroom=HOP, device=dev)
+                info, pk_, nb_, counts = fe.encode_rounds(min_rounds=MAX_ROUNDS, max_rounds=16, headroom=HOP, device=dev,
+                                                          lazy=LAZY_JOIN)
                 round_count[0] += len(counts)
                 round_count[1] += len(info)
+                if LAZY_JOIN:      # the outputs of a call are complete after the next one: keep them alive
+                    kept.append((info, pk_, nb_))
+                    del kept[:-3]
                 return (pk_, nb_) if len(info) else None
             while True:
                 info, pk_, nb_ = fe.encode_round(dev)
@@ -240,6 +248,8 @@ def main():
         return out
 
     def barrier():
+        if fe is not None:
+            fe.join()                # lazy joins: everything begun so far
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()

@@ -170,6 +170,10 @@ int vbm_analysis_round(vbm_encoder *enc, const int *counts, const int *stream_id
 int vbm_analysis_round_begin(vbm_encoder *enc, const int *counts, const int *stream_ids, const uint8_t *wflags,
                              const float *d_pcm, uint8_t *d_packets, int *d_packet_bytes, void *stream);
 int vbm_analysis_round_join(vbm_encoder *enc, void *stream);
+/* ... leaving the newest big batch (>= 1024 blocks of one type) pending: only its front half is waited for; its
+ * back half (floor, couple/quantise, packets: nothing the next round reads) then runs beside the front half of
+ * the next write's big batch.  Its outputs are complete on `stream` after the next lazy join or a full join. */
+int vbm_analysis_round_join_lazy(vbm_encoder *enc, void *stream);
 int vbm_analysis_round_wait_workspace(vbm_encoder *enc, void *stream);
 /* Stage intermediates of the LAST batch as block-major rows ([channel-block][rows]) for parity
  * tests: "mdct_raw" "logfft" "logmdct" "noise" "tone" "logmask" "mdct" "epeak" "npeak" "post"
@@ -265,6 +269,14 @@ int vbm_frontend_encode_round(vbm_frontend *fe, uint8_t *d_packets, int *d_packe
 int vbm_frontend_encode_rounds(vbm_frontend *fe, int min_rounds, int max_rounds, int headroom,
                                uint8_t *d_packets, int *d_packet_bytes, vbm_packet_info *info, int cap_blocks,
                                int *round_blocks, int *nrounds, void *stream);
+/* The same with a lazy join (vbm_analysis_round_join_lazy): the outputs of the call's big batch are complete on
+ * `stream` only after the NEXT vbm_frontend_encode_rounds_lazy call, or vbm_frontend_join; all other outputs as
+ * above.  The caller keeps the output buffers of a call untouched until then.  For throughput: the back half of
+ * one write's long-block batch overlaps the next write. */
+int vbm_frontend_encode_rounds_lazy(vbm_frontend *fe, int min_rounds, int max_rounds, int headroom,
+                                    uint8_t *d_packets, int *d_packet_bytes, vbm_packet_info *info, int cap_blocks,
+                                    int *round_blocks, int *nrounds, void *stream);
+int vbm_frontend_join(vbm_frontend *fe, void *stream);
 
 /* ---- stream wrapper, host only ------------------------------------------------
  * vbm_header_packets = vorbis_analysis_headerout (reference lib/info.c:636-717): the identification,

@@ -42,6 +42,18 @@ def drain(fe, sink, max_rounds=None, multi=False):
     """rounds until no stream has a block (or, with max_rounds, until that many rounds ran and no buffer
     is more than half full); sink[stream] collects (info fields, packet bytes).  multi: through
     vbm_frontend_encode_rounds (several rounds per call, joined at the end)"""
+    if multi == "lazy":
+        # lazy joins: the outputs of a call are complete once the next call has been enqueued (or after join)
+        held = getattr(fe, "_held", None)
+        while True:
+            out = fe.encode_rounds(min_rounds=max_rounds or 64, max_rounds=4 if max_rounds is None else 16, lazy=True)
+            if held is not None:
+                collect(sink, held[0].copy(), held[1], held[2])
+            held = (out[0], out[1], out[2])
+            if not out[3] or max_rounds is not None:
+                break
+        fe._held = held
+        return
     if multi:
         while True:
             info, packets, nbytes, counts = fe.encode_rounds(min_rounds=max_rounds or 64, max_rounds=4 if max_rounds is None else 16)
@@ -131,8 +143,14 @@ def frontend_vs_oracle(oracle, cuda, ch, rate, q, NS, seconds, need_modes=(0, 1,
     for at in range(0, nsamp, 1024):
         fe.write(allp[:, :, at:at + 1024].contiguous())
         drain(fe, got, max_rounds, multi)
+    def flush_held():
+        if getattr(fe, "_held", None) is not None:
+            fe.join()
+            collect(got, fe._held[0].copy(), fe._held[1], fe._held[2])
+            fe._held = None
     # vorbis_analysis_wrote(vd, 0) fits its end-of-stream LPC to what the buffer holds at that moment
     # (lib/block.c:531-541), so, like the reference application loop, drain before finishing
+    flush_held()
     drain(fe, got)
     fe.finish()
     drain(fe, got)
@@ -154,6 +172,42 @@ def test_frontend_multi_round_calls_match_oracle(oracle, cuda, max_rounds):
     """vbm_frontend_encode_rounds: rounds with deferred joins (a round beside the long-block batch of the round
     before, streams changing block type from round to round) — drained completely, and two rounds per write"""
     frontend_vs_oracle(oracle, cuda, 2, 44100, 0.5, NS=200, seconds=1.6, multi=True, max_rounds=max_rounds)
+
+
+def test_frontend_lazy_joins_at_scale(oracle, cuda, monkeypatch):
+    """vbm_frontend_encode_rounds_lazy with a big batch (>= 1024 long blocks per write): its back half stays
+    pending across calls (four workspaces in rotation), outputs are read one call late; 1100 streams carrying
+    5 distinct signals, each compared with the oracle"""
+    import vorbis_aotuv_lancer_amd as v
+    monkeypatch.setenv("VBM_WORKSPACES", "4")
+    K, S, ch, rate, q = 5, 1100, 2, 44100, 0.5
+    nsamp = 30 * 1024
+    base = [synth_signal(ch, rate, nsamp, seed=640 + k, level=1.0 if k % 2 else 0.05) for k in range(K)]
+    sigs = [base[s % K] for s in range(S)]
+    osetup = orc.Setup(oracle, ch, rate, q)
+    want = []
+    for k in range(K):
+        st = orc.Stream(osetup)
+        oracle.lib.orc_stream_set_capture(st.v, 0)
+        seq = []
+        for at in range(0, nsamp, 1024):
+            st.write(base[k][:, at:at + 1024])
+            seq.extend(b["packet"] for b in st.blocks())
+        st.close()
+        want.append(seq)
+    enc = v.Encoder(v.Setup(ch, rate, q), S)
+    fe = v.FrontEnd(enc)
+    got = [[] for _ in range(S)]
+    allp = torch.from_numpy(np.stack(sigs)).to(cuda)
+    for at in range(0, nsamp, 1024):
+        fe.write(allp[:, :, at:at + 1024].contiguous())
+        drain(fe, got, 2, "lazy")
+    fe.join()
+    collect(got, fe._held[0].copy(), fe._held[1], fe._held[2])
+    fe._held = None
+    drain(fe, got)
+    for s in range(S):
+        assert [p for _, p in got[s]] == want[s % K], f"stream {s}"
 
 
 def test_frontend_multi_round_managed(oracle, cuda):

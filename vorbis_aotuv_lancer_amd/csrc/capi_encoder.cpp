@@ -76,6 +76,11 @@ struct vbm_encoder {
     bool done_pending[kMaxWS][4] = {};
     std::vector<signed char> round_type;   // [S] block type of the stream's batch in the last round, -1 none
     bool round_big[4] = {false, false, false, false};   // ... and whether that batch ran on the big-batch stream
+    // A big batch runs its front half (up to offset_and_mix: everything that touches the carried stream state)
+    // on sub[4] and its back half on sub[5], like the two streams of vbm_analysis_batch2: with a lazy join
+    // (vbm_analysis_round_join_lazy) the back half of one write's big batch runs beside the front half of the next.
+    hipEvent_t ev_bigfront = nullptr;
+    int lazy_w = -1, lazy_m = -1;   // the newest big batch (the one a lazy join leaves pending)
     int round_w = -1;                      // workspace of that round
     // the tone-mask branch of a slice runs on its own stream beside the noise-mask branch
     bool overlap_branches = true;
@@ -117,6 +122,7 @@ extern "C" void vbm_encoder_destroy(vbm_encoder *e)
     for (hipEvent_t ev : e->ev_aux_fork) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : e->ev_aux_join) (void)hipEventDestroy(ev);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_bigfront) (void)hipEventDestroy(e->ev_bigfront);
     for (int i = 0; i < kMaxWS; i++)
         for (int m = 0; m < 4; m++)
             if (e->ev_done[i][m]) (void)hipEventDestroy(e->ev_done[i][m]);
@@ -797,7 +803,8 @@ static int analysis_round_impl(vbm_encoder *e, const int *counts, const int *str
     // streams with disjoint CU masks (hipExtStreamCreateWithCUMask) — both slower: the single-wavefront
     // kernels of the small batches run several times slower beside the wide kernels of the big batch, so
     // their chains are better run next to each other than one after another.
-    while ((int)e->sub.size() < 5) {      // one per block type + one for a big batch (see below)
+    if (!e->ev_bigfront && hipEventCreateWithFlags(&e->ev_bigfront, hipEventDisableTiming) != hipSuccess) return VBM_EHIP;
+    while ((int)e->sub.size() < 6) {      // one per block type + two for a big batch (front / back half)
         hipStream_t q;
         hipEvent_t ev;
         if (hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess ||
@@ -841,12 +848,17 @@ static int analysis_round_impl(vbm_encoder *e, const int *counts, const int *str
         RUN(vbm_launch_prologue(&v, q));
         RUN(vbm_launch_noisemask(&v, q));
         RUN(vbm_launch_tonemask(&v, q));
+        if (s->managed) RUN(managed_front(v, q));
+        else { RUN(vbm_launch_mix(&v, q)); RUN(vbm_launch_block_state(&v, q)); }
+        if (bigb) {   // hand over to the back-half stream of big batches
+            if ((err = hipEventRecord(e->ev_bigfront, q)) != hipSuccess ||
+                (err = hipStreamWaitEvent(e->sub[5], e->ev_bigfront, 0)) != hipSuccess)
+                return vbm_set_hip_error(err, "big batch hand-over");
+            q = e->sub[5];
+        }
         if (s->managed) {
-            RUN(managed_front(v, q));
             RUN(managed_back(v, d_packets ? d_packets + (size_t)off[m] * e->max_packet_bytes : nullptr, q));
         } else {
-        RUN(vbm_launch_mix(&v, q));
-        RUN(vbm_launch_block_state(&v, q));
         RUN(vbm_launch_floor_fit(&v, q));
         RUN(vbm_launch_floor_encode(&v, q));
         RUN(vbm_launch_couple_quantize(&v, q));
@@ -885,7 +897,10 @@ static int analysis_round_impl(vbm_encoder *e, const int *counts, const int *str
     for (int m = 0; m < 4; m++)
         if (rcs[m]) { g_vbm_err = msgs[m]; return rcs[m]; }
 #undef RUN
-    for (int m = 0; m < 4; m++) e->round_big[m] = counts[m] >= kBigBatch;
+    for (int m = 0; m < 4; m++) {
+        e->round_big[m] = counts[m] >= kBigBatch;
+        if (e->round_big[m]) { e->lazy_w = w; e->lazy_m = m; }
+    }
     // remember which batch every stream of this round belongs to
     if (e->round_w >= 0) std::fill(e->round_type.begin(), e->round_type.end(), (signed char)-1);
     for (int m = 0; m < 4; m++)
@@ -917,6 +932,29 @@ extern "C" int vbm_analysis_round_join(vbm_encoder *e, void *stream)
                 if (err != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
                 e->done_pending[w][m] = false;
             }
+    return VBM_OK;
+}
+
+// like vbm_analysis_round_join, but the newest big batch stays pending: its back half then runs beside the front
+// half of the next write's big batch.  Its outputs are complete on `stream` after the next lazy join (or a join).
+extern "C" int vbm_analysis_round_join_lazy(vbm_encoder *e, void *stream)
+{
+    if (!e) return VBM_EINVAL;
+    for (int w = 0; w < e->nws; w++)
+        for (int m = 0; m < 4; m++)
+            // also left pending: the batches of the last round — the next round's batches wait for the ones their
+            // own streams were in (the dependency tracking of analysis_round_impl), nothing else needs them yet
+            if (e->done_pending[w][m] && !(w == e->lazy_w && m == e->lazy_m) && w != e->round_w) {
+                hipError_t err = hipStreamWaitEvent((hipStream_t)stream, e->ev_done[w][m], 0);
+                if (err != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
+                e->done_pending[w][m] = false;
+            }
+    // ... but its front half (the part that moves the streams' carried state on) has to be done before anything
+    // enqueued on `stream` later: the next rounds are forked from there
+    if (e->lazy_w >= 0 && e->done_pending[e->lazy_w][e->lazy_m] && e->ev_bigfront) {
+        hipError_t err = hipStreamWaitEvent((hipStream_t)stream, e->ev_bigfront, 0);
+        if (err != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
+    }
     return VBM_OK;
 }
 

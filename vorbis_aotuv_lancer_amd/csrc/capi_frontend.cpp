@@ -435,9 +435,9 @@ extern "C" int vbm_frontend_encode_round(vbm_frontend *fe, uint8_t *d_packets, i
 // batch of the previous round.  Rounds stop when none produced a block, after max_rounds, when fewer than
 // nstreams output slots are left, or — past min_rounds — once every stream could take `headroom` more samples
 // without its buffer passing half full.  Outputs are compact over the rounds, in round order.
-extern "C" int vbm_frontend_encode_rounds(vbm_frontend *fe, int min_rounds, int max_rounds, int headroom,
-                                          uint8_t *d_packets, int *d_packet_bytes, vbm_packet_info *info,
-                                          int cap_blocks, int *round_blocks, int *nrounds, void *stream)
+static int encode_rounds_impl(vbm_frontend *fe, int min_rounds, int max_rounds, int headroom,
+                              uint8_t *d_packets, int *d_packet_bytes, vbm_packet_info *info,
+                              int cap_blocks, int *round_blocks, int *nrounds, void *stream, bool lazy)
 {
     if (!fe || !info || !nrounds || max_rounds < 1 || min_rounds < 0 || cap_blocks < 0) return VBM_EINVAL;
     *nrounds = 0;
@@ -479,6 +479,29 @@ extern "C" int vbm_frontend_encode_rounds(vbm_frontend *fe, int min_rounds, int 
         *nrounds = r + 1;
     }
     fe->hold_active = false;
-    int rj = vbm_analysis_round_join(vbm_frontend_encoder(fe), stream);
+    int rj = lazy ? vbm_analysis_round_join_lazy(vbm_frontend_encoder(fe), stream)
+                  : vbm_analysis_round_join(vbm_frontend_encoder(fe), stream);
     return rc ? rc : rj;
+}
+
+extern "C" int vbm_frontend_encode_rounds(vbm_frontend *fe, int min_rounds, int max_rounds, int headroom,
+                                          uint8_t *d_packets, int *d_packet_bytes, vbm_packet_info *info,
+                                          int cap_blocks, int *round_blocks, int *nrounds, void *stream)
+{
+    return encode_rounds_impl(fe, min_rounds, max_rounds, headroom, d_packets, d_packet_bytes, info, cap_blocks, round_blocks,
+                              nrounds, stream, false);
+}
+
+extern "C" int vbm_frontend_encode_rounds_lazy(vbm_frontend *fe, int min_rounds, int max_rounds, int headroom,
+                                               uint8_t *d_packets, int *d_packet_bytes, vbm_packet_info *info,
+                                               int cap_blocks, int *round_blocks, int *nrounds, void *stream)
+{
+    return encode_rounds_impl(fe, min_rounds, max_rounds, headroom, d_packets, d_packet_bytes, info, cap_blocks, round_blocks,
+                              nrounds, stream, true);
+}
+
+extern "C" int vbm_frontend_join(vbm_frontend *fe, void *stream)
+{
+    if (!fe) return VBM_EINVAL;
+    return vbm_analysis_round_join(fe->enc, stream);
 }

@@ -222,14 +222,19 @@ class FrontEnd:
         k = n.value
         return self._info_view[:k], packets[:k], nbytes[:k]
 
-    def encode_rounds(self, min_rounds=1, max_rounds=8, headroom=1024, device=None):
+    def join(self):
+        """vbm_frontend_join: the current stream waits for everything begun so far (lazy calls included)"""
+        check(lib.vbm_frontend_join(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "vbm_frontend_join")
+
+    def encode_rounds(self, min_rounds=1, max_rounds=8, headroom=1024, device=None, lazy=False):
         """Up to max_rounds blockout rounds in one call (vbm_frontend_encode_rounds: a round runs beside the
         long-block batch of the round before it; everything is joined at the end).  Returns (info records,
         packets uint8 [n, max_bytes], nbytes int32 [n], blocks per round) over all rounds, in round order."""
         dev = device or torch.device("cuda", torch.cuda.current_device())
         S = self.enc.nstreams
         cap = S * max_rounds
-        if getattr(self, "_multi_cap", 0) < cap:
+        if getattr(self, "_multi_cap", 0) < cap or lazy:
+            # lazy: the records of a call stay valid while the next call fills its own
             self._multi_info = (PacketInfo * cap)()
             self._multi_view = np.ctypeslib.as_array(self._multi_info)
             self._multi_cap = cap
@@ -238,9 +243,9 @@ class FrontEnd:
         per_round = (C.c_int * max_rounds)()
         nr = C.c_int()
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        check(lib.vbm_frontend_encode_rounds(self._h, min_rounds, max_rounds, headroom, packets.data_ptr(), nbytes.data_ptr(),
-                                             self._multi_info, cap, per_round, C.byref(nr), st),
-              "vbm_frontend_encode_rounds")
+        fn = lib.vbm_frontend_encode_rounds_lazy if lazy else lib.vbm_frontend_encode_rounds
+        check(fn(self._h, min_rounds, max_rounds, headroom, packets.data_ptr(), nbytes.data_ptr(),
+                 self._multi_info, cap, per_round, C.byref(nr), st), "vbm_frontend_encode_rounds")
         counts = [per_round[r] for r in range(nr.value)]
         k = sum(counts)
         return self._multi_view[:k], packets[:k], nbytes[:k], counts
