@@ -47,7 +47,8 @@ N_LONG = 2048
 HOP = N_LONG // 2
 SPLIT = int(os.environ.get("VBM_BENCH_SPLIT", "1"))   # sub-batches per step, one HIP stream each
 TWO_STREAMS = os.environ.get("VBM_BENCH_TWO_STREAMS", "1") != "0"   # vbm_analysis_batch2: front / back half streams
-MAX_ROUNDS = int(os.environ.get("VBM_BENCH_MAX_ROUNDS", "2"))   # --from-pcm: blockout rounds per write
+MAX_ROUNDS = int(os.environ.get("VBM_BENCH_MAX_ROUNDS", "1"))   # --from-pcm: blockout rounds per write before the
+                                                                 # buffers decide (more while one is past half full)
 DISTINCT_STEPS = 8              # PCM for this many consecutive blocks per stream is kept in HBM
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
