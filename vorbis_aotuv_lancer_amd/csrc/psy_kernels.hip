@@ -124,6 +124,7 @@ __global__ void k_prologue(vbm_batch b)
 //   k_nm_post          compander, M2 post-echo, M8, M9: independent per normal-partition, sliced
 //                      over blockIdx.y in units of partitions.
 #define HY_PF 16
+static_assert(HY_PF == 16, "k_nm_prefix keeps the last row of every HY_PF batch as the checkpoint");
 #define NM_C 16     // checkpoint interval of the five running sums (rows NM_C-1, 2*NM_C-1, ... are stored)
 
 struct hy_bounds { int i1, i2, f1, f2; };
@@ -153,41 +154,63 @@ __device__ __forceinline__ void prefix_chain(const vbm_batch &b, const vbm_psy *
     const int n25p = p->n25p, n75p = p->n75p;
     const int rb = p->hy_rb;
 
-    for (int i = 0; i < n; i += HY_PF) {
+    // one bin: logmdct (pass 1), the term of this chain, the running sum
+    auto bin = [&](float v, const int k) {
+        if (PASS == 1) {
+            v = (float)((double)vbm_todB(v) + .345);   // logmdct, lib/mapping0.c:936
+            if (CHAIN == 0) {
+                T(logmdct, k) = v;
+                if (k >= n25p && k < n75p) hi_th += (v > -130) ? (double)v : -130.;
+            }
+        }
+        float y = v + offset;
+        if (y < 1.f) y = 1.f;
+        float w = y * y;
+        if (k == 0) {
+            // first element, lib/psy.c:3497-3507: half weight, x = 0 (X takes w, XX and XY nothing)
+            w = (float)((double)w * .5);
+            if (CHAIN == 0 || CHAIN == 1) acc += w;
+            if (CHAIN == 3) acc += w * y;
+        } else {
+            if (CHAIN == 0) acc += w;
+            if (CHAIN == 1) acc += w * x;
+            if (CHAIN == 2) acc += w * x * x;
+            if (CHAIN == 3) acc += w * y;
+            if (CHAIN == 4) acc += w * x * y;
+        }
+        x += 1.f;
+    };
+    // rows below rb (a multiple of HY_PF): every row is kept, for the mirrored window edges
+    int i = 0;
+    for (; i < rb && i < n; i += HY_PF) {
         float fv[HY_PF];
 #pragma unroll
         for (int u = 0; u < HY_PF; u++) fv[u] = T(src, (i + u < n) ? i + u : n - 1);   // unconditional, clamped
 #pragma unroll
-        for (int u = 0; u < HY_PF; u++) {
+        for (int u = 0; u < HY_PF; u++)
             if (i + u < n) {
-                float v = fv[u];
-                if (PASS == 1) {
-                    v = (float)((double)vbm_todB(v) + .345);   // logmdct, lib/mapping0.c:936
-                    if (CHAIN == 0) {
-                        T(logmdct, i + u) = v;
-                        if (i + u >= n25p && i + u < n75p) hi_th += (v > -130) ? (double)v : -130.;
-                    }
-                }
-                float y = v + offset;
-                if (y < 1.f) y = 1.f;
-                float w = y * y;
-                if (i + u == 0) {
-                    // first element, lib/psy.c:3497-3507: half weight, x = 0 (X takes w, XX and XY nothing)
-                    w = (float)((double)w * .5);
-                    if (CHAIN == 0 || CHAIN == 1) acc += w;
-                    if (CHAIN == 3) acc += w * y;
-                } else {
-                    if (CHAIN == 0) acc += w;
-                    if (CHAIN == 1) acc += w * x;
-                    if (CHAIN == 2) acc += w * x * x;
-                    if (CHAIN == 3) acc += w * y;
-                    if (CHAIN == 4) acc += w * x * y;
-                }
-                // kept: the rows mirrored window edges read directly, and every NM_C-th row as a checkpoint
-                // the solve restarts its running sums from (k_nm_solve)
-                if (i + u < rb || ((i + u) & (NM_C - 1)) == NM_C - 1) T(dst, (i + u) * 5) = acc;
-                x += 1.f;
+                bin(fv[u], i + u);
+                T(dst, (i + u) * 5) = acc;
             }
+    }
+    // the rest: only the last row of a batch is kept, as a checkpoint the solve restarts its running sums from
+    // (k_nm_solve).  Loads and stores retire in order, so the next batch's loads are issued BEFORE this batch's
+    // stores (a fixed number of them): the wait for the loads then does not include the stores.
+    if (i < n) {
+        float cur[HY_PF];
+#pragma unroll
+        for (int u = 0; u < HY_PF; u++) cur[u] = T(src, (i + u < n) ? i + u : n - 1);
+        for (; i < n; i += HY_PF) {
+            float nxt[HY_PF];
+            const int in = (i + HY_PF < n) ? i + HY_PF : i;
+#pragma unroll
+            for (int u = 0; u < HY_PF; u++) nxt[u] = T(src, (in + u < n) ? in + u : n - 1);
+#pragma unroll
+            for (int u = 0; u < HY_PF; u++)
+                if (i + u < n) bin(cur[u], i + u);
+            T(dst, (((i + HY_PF < n) ? i + HY_PF : n) - 1) * 5) = acc;
+#pragma unroll
+            for (int u = 0; u < HY_PF; u++) cur[u] = nxt[u];
         }
     }
 
