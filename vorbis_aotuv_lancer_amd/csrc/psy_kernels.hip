@@ -981,6 +981,66 @@ __device__ __forceinline__ void mix_body(const vbm_batch &b, const int nchunks, 
     const float *__restrict__ noiseoffset = p->noiseoffset[offset_select];
     const float noisemaxsupp = p->noisemaxsupp, m_val = p->m_val;
     const int tonecomp_endp = p->tonecomp_endp, m3n0 = p->m3n[0], m3n1 = p->m3n[1], m3n2 = p->m3n[2];
+    // Without M3 (every block type but impulse) the bins are independent: eight bins' inputs are read before
+    // anything is written, so the loads of a bin do not queue behind the stores of the one before it (loads and
+    // stores retire in order) — the kernel is latency-bound, 64 dependent round trips per slice otherwise.
+    // M3 SET's plain copies lastmdct[i] = logmdct[i] (lib/psy.c:4463-4501) ride along
+    const bool copy_last = mp3.mdctbuf_flag == 1 && !mp3.sw &&
+                           ((block_mode <= 1 && !nW_modenumber) || (block_mode == 2 && nW_modenumber) || block_mode == 3);
+    if (!mp3.sw) {
+        for (i = i0; i < i1; i += 8) {
+            float nv[8], tv[8], lv[8], mv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int ii = (i + u < i1) ? i + u : i1 - 1;
+                nv[u] = T(noise, ii);
+                tv[u] = T(tone, ii);
+                lv[u] = T(logmdct, ii);
+                if (SEL == 1) mv[u] = T(mdct, ii);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int ii = i + u;
+                if (ii < i1) {
+                    float val = nv[u] + noiseoffset[ii];
+                    float tval = tv[u] + toneatt;
+                    const float lm = lv[u];
+                    if (ii <= m4_start) tval -= low_compand;
+                    if (val > noisemaxsupp) val = noisemaxsupp;
+                    // M4 MAIN
+                    float lmv;
+                    if (val > tval) {
+                        lmv = val;
+                    } else if ((ii > m4_start) && (ii < m4_end)) {
+                        if (lm < tval) {
+                            if (lm < val) tval -= (tval - val) * m4_thres;
+                            else tval = lm;
+                        }
+                        lmv = tval;
+                    } else
+                        lmv = tval;
+                    T(logmask, ii) = lmv;
+                    if (copy_last) LAST(ii) = lm;
+                    if (QF) {   // vorbis_dBquant (lib/floor1.c:294) and the two-fit test (lib/floor1.c:452)
+                        int q = (int)(lmv * 7.3142857f + 1023.5f);
+                        q = q > 1023 ? 1023 : (q < 0 ? 0 : q);
+                        qtile[ii - i0][threadIdx.x] = (uint16_t)(q | ((lm + twofitatten >= lmv) ? 0x8000 : 0));
+                    }
+                    // M1 (offset_select == 1)
+                    if (SEL == 1) {
+                        m1_coeffi = (float)-17.2;
+                        val = val - lm;
+                        if (val > m1_coeffi) {
+                            m1_de = (float)(1.0 - ((double)(val - m1_coeffi) * 0.005 * (double)m_val));
+                            if (m1_de < 0) m1_de = (float)0.0001;
+                        } else
+                            m1_de = (float)(1.0 - ((double)(val - m1_coeffi) * 0.0003 * (double)m_val));
+                        T(mdct, ii) = mv[u] * m1_de;
+                    }
+                }
+            }
+        }
+    } else
     for (i = i0; i < i1; i++) {
         float val = T(noise, i) + noiseoffset[i];
         float tval = T(tone, i) + toneatt;
@@ -1075,7 +1135,7 @@ __device__ __forceinline__ void mix_body(const vbm_batch &b, const int nchunks, 
     }
 
     // M3 SET lastmdct
-    if (mp3.mdctbuf_flag == 1) {
+    if (mp3.mdctbuf_flag == 1 && !copy_last) {
         const int mag = 8;
         switch (block_mode) {
         case 0:
