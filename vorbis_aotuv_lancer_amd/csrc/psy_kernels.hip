@@ -809,24 +809,34 @@ __global__ void k_tm_apply(vbm_batch b, int nchunks)
 
     int q0 = -2, q1 = -2;
     float minV = 0.f;
-    for (int i = c0; i < c1; i++) {
-        const int p0 = seg_p0[i], p1 = seg_p1[i];
-        if (p0 != q0 || p1 != q1) {
-            q0 = p0; q1 = p1;
-            if (p0 < 0) {
-                minV = T(seed, tn - 1);
-            } else {
-                minV = T(seed, p0);
-                if (minV > tone_abs_limit) minV = tone_abs_limit;
-                for (int pos = p0 + 1; pos <= p1; pos++) {
-                    float sv = T(seed, pos);
-                    if ((sv > NEGINF && sv < minV) || minV == NEGINF) minV = sv;
+    // eight bins' values first, then their stores: the seed loads of a bin do not queue behind the store of the
+    // bin before it (loads and stores retire in order)
+    for (int i = c0; i < c1; i += 8) {
+        float out[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int ii = (i + u < c1) ? i + u : c1 - 1;
+            const int p0 = seg_p0[ii], p1 = seg_p1[ii];
+            if (p0 != q0 || p1 != q1) {
+                q0 = p0; q1 = p1;
+                if (p0 < 0) {
+                    minV = T(seed, tn - 1);
+                } else {
+                    minV = T(seed, p0);
+                    if (minV > tone_abs_limit) minV = tone_abs_limit;
+                    for (int pos = p0 + 1; pos <= p1; pos++) {
+                        float sv = T(seed, pos);
+                        if ((sv > NEGINF && sv < minV) || minV == NEGINF) minV = sv;
+                    }
                 }
             }
+            float v = ath[ii] + att;
+            if (v < minV) v = minV;
+            out[u] = v;
         }
-        float v = ath[i] + att;
-        if (v < minV) v = minV;
-        T(flr, i) = v;
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (i + u < c1) T(flr, i + u) = out[u];
     }
 }
 
