@@ -517,20 +517,49 @@ __global__ void k_nm_post(vbm_batch b, int nchunks)
     const float *__restrict__ noiseoffset1 = p->noiseoffset[1];
     const int min_nn_lp = p->min_nn_lp;
 
-    // noise compand & aoTuV M5 extension & pre-store tone peak
+    // noise compand & aoTuV M5 extension & tone peak, and M9 with it: M9 (lib/psy.c:4058-4072) replaces the tone
+    // peak of every bin by a value that depends on that peak, logmdct and lastmdct only — nothing in between
+    // reads the intermediate peak — so the final value is stored here and the bins are walked once.  Eight bins'
+    // inputs are read before anything is written (loads and stores retire in order).
     {
         const int thter = (noise_compand_level > 0) ? p->n33p : 0;
-        for (i = c0; i < c1; i++) {
-            int dB = (int)((double)T(logmask, i) + .5);
-            if (dB >= VBM_NOISE_COMPAND_LEVELS) dB = VBM_NOISE_COMPAND_LEVELS - 1;
-            if (dB < 0) dB = 0;
-            const float wv = T(work, i);
-            T(epeak, i) = wv + stn_compand[dB];
-            if (i < thter)
-                T(logmask, i) = wv + noisecompand[dB] -
-                                ((noisecompand[dB] - noisecompand_high[dB]) * noise_compand_level);
-            else
-                T(logmask, i) = wv + noisecompand[dB];
+        const float *lastmdct = b.st.mblock + (size_t)(col >> 6) * b.st.slab_words + (col & 63);
+        const int m9_end = (b.block_mode > 1) ? p->tonecomp_endp : 0;
+        for (i = c0; i < c1; i += 8) {
+            float lmk[8], wvv[8], lmd[8], lst[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int ii = (i + u < c1) ? i + u : c1 - 1;
+                lmk[u] = T(logmask, ii);
+                wvv[u] = T(work, ii);
+                lmd[u] = T(logmdct, ii);
+                lst[u] = (ii < m9_end) ? lastmdct[(size_t)ii * 64] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int ii = i + u;
+                if (ii < c1) {
+                    int dB = (int)((double)lmk[u] + .5);
+                    if (dB >= VBM_NOISE_COMPAND_LEVELS) dB = VBM_NOISE_COMPAND_LEVELS - 1;
+                    if (dB < 0) dB = 0;
+                    const float wv = wvv[u];
+                    const float ep = wv + stn_compand[dB];
+                    if (ii < thter)
+                        T(logmask, ii) = wv + noisecompand[dB] -
+                                         ((noisecompand[dB] - noisecompand_high[dB]) * noise_compand_level);
+                    else
+                        T(logmask, ii) = wv + noisecompand[dB];
+                    float e = 0.f;
+                    if (ii < m9_end) {
+                        float temp = lmd[u] - ep;
+                        if (temp >= 12.f) {
+                            float mi = lmd[u] - lst[u];
+                            if (mi >= 1) e = mi;
+                        }
+                    }
+                    T(epeak, ii) = e;
+                }
+            }
         }
     }
 
@@ -567,22 +596,6 @@ __global__ void k_nm_post(vbm_batch b, int nchunks)
         if (me < nt) T(npeak, k) = (VMIN(o, nt - me)) / nt;
     }
 
-    // M9
-    {
-        const float *lastmdct = b.st.mblock;
-        const int m9_end = (b.block_mode > 1) ? p->tonecomp_endp : 0;
-        for (i = c0; i < c1; i++) {
-            float e = 0.f;
-            if (i < m9_end) {
-                float temp = T(logmdct, i) - T(epeak, i);
-                if (temp >= 12.f) {
-                    float mi = T(logmdct, i) - lastmdct[(size_t)(col >> 6) * b.st.slab_words + (size_t)i * 64 + (col & 63)];
-                    if (mi >= 1) e = mi;
-                }
-            }
-            T(epeak, i) = e;
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
