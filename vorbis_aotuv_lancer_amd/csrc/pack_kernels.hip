@@ -710,18 +710,29 @@ __global__ void k_res_emit(vbm_batch b, int sm, int nchunks)
                 int wi = pos >> 5;
                 int nbits = pos & 31;   // bits below the run's start stay zero in acc
                 uint64_t acc = 0;
-                for (int t = 0; t < v.spp && remaining > 0; t++) {
-                    const uint64_t cw = sl[(size_t)t * 64];
-                    const int len = (int)(cw >> 32);
-                    if (!len) continue;
-                    acc |= (uint64_t)(uint32_t)cw << nbits;
-                    nbits += len;
-                    remaining -= len;
-                    if (nbits >= 32) {
-                        if (wi < maxwords) atomicOr(&words[(size_t)wi * 64], (uint32_t)acc);
-                        acc >>= 32;
-                        nbits -= 32;
-                        wi++;
+                // eight codeword slots are read before any of their bits go out (the loads would otherwise queue
+                // behind the atomics of the slot before: loads and stores retire in order)
+                for (int t0 = 0; t0 < v.spp && remaining > 0; t0 += 8) {
+                    uint64_t cwv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) cwv[u] = sl[(size_t)((t0 + u < v.spp) ? t0 + u : v.spp - 1) * 64];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        if (t0 + u < v.spp && remaining > 0) {
+                            const uint64_t cw = cwv[u];
+                            const int len = (int)(cw >> 32);
+                            if (len) {
+                                acc |= (uint64_t)(uint32_t)cw << nbits;
+                                nbits += len;
+                                remaining -= len;
+                                if (nbits >= 32) {
+                                    if (wi < maxwords) atomicOr(&words[(size_t)wi * 64], (uint32_t)acc);
+                                    acc >>= 32;
+                                    nbits -= 32;
+                                    wi++;
+                                }
+                            }
+                        }
                     }
                 }
                 if (nbits > 0 && wi < maxwords) atomicOr(&words[(size_t)wi * 64], (uint32_t)acc);
