@@ -653,6 +653,48 @@ __global__ void k_res_offsets(vbm_batch b, int sm)
         const vbm_book *phrasebook = &s->book[r->groupbook];
         const int partitions_per_word = r->phrase_dim;
         // emission order of _01forward, lib/res0.c:574-636
+        if (v.used == 1 && partitions_per_word == 2) {
+            // one coded vector (res2) and two partitions per phrase word: eight words' classes, phrase codewords
+            // and run lengths are read before any of their offsets / phrase bits is written (the loads would
+            // queue behind the stores and atomics of the word before: loads and stores retire in order)
+            const signed char *__restrict__ pll = phrasebook->lengthlist;
+            const uint32_t *__restrict__ pcl = phrasebook->codelist;
+            const int pents = phrasebook->entries, nparts = r->partitions, pv = v.partvals;
+            for (int st = 0; st < r->stages; st++) {
+                for (int i = 0; i < pv; i += 16) {
+                    int plen[8], l0[8], l1[8];
+                    uint32_t pcode[8];
+#pragma unroll
+                    for (int g = 0; g < 8; g++) {
+                        const int ia = i + 2 * g, ib = ia + 1;
+                        plen[g] = 0; pcode[g] = 0;
+                        if (st == 0 && ia < pv) {
+                            long val = (long)PW(0, ia) * nparts;
+                            if (ib < pv) val += PW(0, ib);
+                            if (val < pents) { plen[g] = pll[val]; pcode[g] = pcl[val]; }
+                        }
+                        l0[g] = (ia < pv) ? LEN(st, 0, ia) : 0;
+                        l1[g] = (ib < pv) ? LEN(st, 0, ib) : 0;
+                    }
+#pragma unroll
+                    for (int g = 0; g < 8; g++) {
+                        const int ia = i + 2 * g, ib = ia + 1;
+                        if (ia < pv) {
+                            if (st == 0 && plen[g] > 0) {
+                                or_bits(words, maxwords, pos, pcode[g], plen[g]);
+                                pos += plen[g];
+                            }
+                            OFF(st, 0, ia) = pos;
+                            pos += l0[g];
+                            if (ib < pv) {
+                                OFF(st, 0, ib) = pos;
+                                pos += l1[g];
+                            }
+                        }
+                    }
+                }
+            }
+        } else
         for (int st = 0; st < r->stages; st++) {
             for (int i = 0; i < v.partvals;) {
                 if (st == 0) {
