@@ -295,6 +295,11 @@ __global__ void k_pack_head(vbm_batch b)
             int cval = 0;
             int cshift = 0;
             int l;
+            // the partition's values, then its codewords, are fetched together before any bit is written (the
+            // packet stores would otherwise sit between dependent loads: loads and stores retire in order)
+            int ov[8];
+#pragma unroll
+            for (k = 0; k < 8; k++) ov[k] = (k < cdim) ? OUTV(j + k) : 0;
 
             if (csubbits) {
                 int maxval[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -303,27 +308,41 @@ __global__ void k_pack_head(vbm_batch b)
                     if (booknum < 0) maxval[k] = 1;
                     else maxval[k] = s->book[booknum].entries;
                 }
-                for (k = 0; k < cdim; k++) {
-                    for (l = 0; l < csub; l++) {
-                        int val = OUTV(j + k);
-                        if (val < maxval[l]) {
-                            bookas[k] = l;
-                            break;
+#pragma unroll
+                for (k = 0; k < 8; k++) {
+                    if (k < cdim) {
+                        for (l = 0; l < csub; l++) {
+                            if (ov[k] < maxval[l]) {
+                                bookas[k] = l;
+                                break;
+                            }
+                        }
+                        cval |= bookas[k] << cshift;
+                        cshift += csubbits;
+                    }
+                }
+            }
+            int blen[8];
+            uint32_t bcode[8];
+#pragma unroll
+            for (k = 0; k < 8; k++) {
+                blen[k] = 0;
+                bcode[k] = 0;
+                if (k < cdim) {
+                    const int book = look->class_subbook[cls][bookas[k]];
+                    if (book >= 0) {
+                        const vbm_book *bk = &s->book[book];
+                        if (ov[k] >= 0 && ov[k] < bk->entries) {
+                            blen[k] = bk->lengthlist[ov[k]];
+                            bcode[k] = bk->codelist[ov[k]];
                         }
                     }
-                    cval |= bookas[k] << cshift;
-                    cshift += csubbits;
-                }
-                book_encode(&s->book[look->class_book[cls]], cval, w);
-            }
-
-            for (k = 0; k < cdim; k++) {
-                int book = look->class_subbook[cls][bookas[k]];
-                if (book >= 0) {
-                    int val = OUTV(j + k);
-                    if (val < s->book[book].entries) book_encode(&s->book[book], val, w);
                 }
             }
+            if (csubbits) book_encode(&s->book[look->class_book[cls]], cval, w);
+#pragma unroll
+            for (k = 0; k < 8; k++)
+                if (k < cdim && blen[k] > 0) bw_write(w, bcode[k], blen[k]);
             j += cdim;
         }
 #undef OUTV
