@@ -43,7 +43,7 @@ const char *vbm_last_error(void);
  * rising half-windows the block size can meet (lib/window.c:29-2122; b->window[W],
  * lib/block.c:218-219) so that windowing fuses into the transform.
  *
- *   n        transform size: 2048 (long) or 256 (short) in this release
+ *   n        transform size: 256, 512, 1024, 2048 or 4096 (the block sizes of the shipped mode families)
  *   short_n  size of the short block of the same mode pair (for n==2048: 256); the
  *            left/right window halves of a long block next to a short one use it
  *   win_n / win_short: host pointers to the rising half-windows (n/2 and short_n/2
@@ -125,9 +125,11 @@ int vbm_setup_table(const vbm_setup_handle *setup, const char *name, const void 
  *   d_pcm        device, [nsb][channels][blocksize] floats: vb->pcm as vorbis_analysis_blockout
  *                hands it over (un-windowed, lib/block.c:653-698)
  *   d_packets    device, [nsb][vbm_encoder_max_packet_bytes()] bytes: op->packet of every block
- *   d_packet_bytes device, [nsb] ints: op->bytes (or -1 if a packet outgrew the buffer)
- * Managed-bitrate mode (15 packetblobs) is not implemented: VBM_EIMPL from create if the mode
- * pack asks for it. */
+ *   d_packet_bytes device, [nsb] ints: op->bytes, or -1 if a packet outgrew max_packet_bytes — check it
+ *                before using the row (its bytes are then incomplete)
+ * A stream id may appear ONCE per call: the blocks of a stream are order dependent and two of them in one
+ * batch would race on the carried state; duplicates are rejected with VBM_EINVAL.
+ * Managed-bitrate setups (15 packetblobs + reservoirs) go through the same calls: see "Managed bitrate" below. */
 typedef struct vbm_encoder vbm_encoder;
 int vbm_encoder_create(vbm_encoder **enc, vbm_setup_handle *setup, int nstreams, int max_batch);
 void vbm_encoder_destroy(vbm_encoder *enc);
@@ -260,6 +262,17 @@ int vbm_frontend_max_buffered(const vbm_frontend *fe);
 int vbm_frontend_capacity(const vbm_frontend *fe);
 int vbm_frontend_encode_round(vbm_frontend *fe, uint8_t *d_packets, int *d_packet_bytes,
                               vbm_packet_info *info, int *nblocks, void *stream);
+/* One round for the listed streams only: every other stream is left alone (no block, no state change), as if
+ * its application had not asked vorbis_analysis_blockout yet.  Outputs as vbm_frontend_encode_round. */
+int vbm_frontend_encode_round_streams(vbm_frontend *fe, const int *stream_ids, int n, uint8_t *d_packets,
+                                      int *d_packet_bytes, vbm_packet_info *info, int *nblocks, void *stream);
+/* Packets for a host consumer: the rows d_packets[k][max_packet_bytes] with d_packet_bytes[k] bytes used (k < n)
+ * as one byte run in d_out, packet k at d_offsets[k] (4-byte aligned, exclusive prefix sum of the padded
+ * lengths), d_offsets[n] = bytes of d_out used; negative lengths count as 0.  d_out needs n * max_packet_bytes
+ * bytes in the worst case, d_offsets n + 1 entries.  One D2H copy of d_offsets[n] bytes then replaces n row
+ * copies (what vorbis_bitrate_flushpacket's ogg_packet needs on the host, reference lib/bitrate.c:229-252). */
+int vbm_packets_compact(const uint8_t *d_packets, const int *d_packet_bytes, int n, int max_packet_bytes,
+                        uint8_t *d_out, long long *d_offsets, void *stream);
 /* Up to max_rounds rounds in one call (deferred joins: vbm_analysis_round_begin), results complete on `stream`
  * when the call's work has run: packets / lengths / infos of all rounds, compact, in round order;
  * round_blocks[r] = blocks of round r, *nrounds = rounds that produced blocks.  Rounds stop when one produces

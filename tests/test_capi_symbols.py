@@ -12,6 +12,26 @@ def declared_symbols():
     return sorted(set(re.findall(r"\b(vbm_[a-z0-9_]+)\s*\(", text)))
 
 
+def compat_symbols():
+    text = open(os.path.join(ROOT, "include", "vorbis_compat.h")).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    return sorted(set(re.findall(r"\b((?:vorbis|ogg)_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_the_references_entry_points():
+    """include/vorbis_compat.h: vorbis_analysis, vorbis_bitrate_addblock/_flushpacket and their feeders under the
+    reference's own names (include/vorbis/codec.h:164-198)."""
+    import vorbis_aotuv_lancer_amd as v
+    syms = compat_symbols()
+    for need in ("vorbis_analysis", "vorbis_bitrate_addblock", "vorbis_bitrate_flushpacket", "vorbis_analysis_init",
+                 "vorbis_analysis_buffer", "vorbis_analysis_wrote", "vorbis_analysis_blockout", "vorbis_block_init",
+                 "vorbis_block_clear", "vorbis_dsp_clear", "vorbis_encode_init_vbr", "vorbis_analysis_headerout"):
+        assert need in syms
+    dll = ctypes.CDLL(v.LIB_PATH)
+    missing = [s for s in syms if not hasattr(dll, s)]
+    assert not missing, missing
+
+
 def test_library_exports_every_declared_symbol():
     import vorbis_aotuv_lancer_amd as v
     syms = declared_symbols()

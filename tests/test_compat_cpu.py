@@ -1,0 +1,115 @@
+"""include/vorbis_compat.h without a GPU: the public struct layouts are the reference's
+(include/vorbis/codec.h:27-149, LP64), the host-only entry points behave like the reference's, and the device
+entry points fail loudly instead of falling back to a CPU path."""
+import ctypes as C
+import os
+import subprocess
+
+import pytest
+
+from tests import compat
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# field offsets of the reference's structs on LP64 (x86-64 / the GPU box), derived from the field lists of
+# include/vorbis/codec.h:27-53 (vorbis_info), :58-85 (vorbis_dsp_state), :87-119 (vorbis_block),
+# :141-149 (vorbis_comment) and libogg's oggpack_buffer / ogg_packet
+LAYOUT = {
+    "vorbis_info": (56, {"version": 0, "channels": 4, "rate": 8, "bitrate_upper": 16, "bitrate_nominal": 24,
+                         "bitrate_lower": 32, "bitrate_window": 40, "codec_setup": 48}),
+    "vorbis_dsp_state": (144, {"analysisp": 0, "vi": 8, "pcm": 16, "pcmret": 24, "pcm_storage": 32, "pcm_current": 36,
+                               "pcm_returned": 40, "preextrapolate": 44, "eofflag": 48, "lW": 56, "W": 64, "nW": 72,
+                               "centerW": 80, "granulepos": 88, "sequence": 96, "glue_bits": 104, "time_bits": 112,
+                               "floor_bits": 120, "res_bits": 128, "backend_state": 136}),
+    "vorbis_block": (192, {"pcm": 0, "opb": 8, "lW": 48, "W": 56, "nW": 64, "pcmend": 72, "mode": 76, "eofflag": 80,
+                           "granulepos": 88, "sequence": 96, "vd": 104, "localstore": 112, "localtop": 120,
+                           "localalloc": 128, "totaluse": 136, "reap": 144, "glue_bits": 152, "time_bits": 160,
+                           "floor_bits": 168, "res_bits": 176, "internal": 184}),
+    "vorbis_comment": (32, {"user_comments": 0, "comment_lengths": 8, "comments": 16, "vendor": 24}),
+    "oggpack_buffer": (40, {"endbyte": 0, "endbit": 8, "buffer": 16, "ptr": 24, "storage": 32}),
+    "ogg_packet": (48, {"packet": 0, "bytes": 8, "b_o_s": 16, "e_o_s": 24, "granulepos": 32, "packetno": 40}),
+}
+
+
+def test_public_struct_layouts(tmp_path):
+    """offsetof() of every field as a C compiler sees include/vorbis_compat.h"""
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "vorbis_compat.h"', 'int main(void){']
+    for st, (size, fields) in LAYOUT.items():
+        src.append(f'printf("{st} %zu\\n", sizeof({st}));')
+        for f in fields:
+            src.append(f'printf("{st}.{f} %zu\\n", offsetof({st}, {f}));')
+    src.append('return 0;}')
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)])
+    got = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for st, (size, fields) in LAYOUT.items():
+        assert int(got[st]) == size, st
+        for f, off in fields.items():
+            assert int(got[f"{st}.{f}"]) == off, (st, f)
+    # the ctypes mirror the GPU tests use agrees as well
+    for st, cls in (("vorbis_info", compat.VorbisInfo), ("vorbis_dsp_state", compat.VorbisDspState),
+                    ("vorbis_block", compat.VorbisBlock), ("vorbis_comment", compat.VorbisComment),
+                    ("oggpack_buffer", compat.OggpackBuffer), ("ogg_packet", compat.OggPacket)):
+        assert C.sizeof(cls) == LAYOUT[st][0]
+        for f, off in LAYOUT[st][1].items():
+            assert getattr(cls, f).offset == off, (st, f)
+
+
+@pytest.fixture(scope="module")
+def dll():
+    import vorbis_aotuv_lancer_amd as v
+    return compat.bind(C.CDLL(v.LIB_PATH))
+
+
+def test_setup_selection_and_errors(dll):
+    vi = compat.VorbisInfo()
+    dll.vorbis_info_init(vi)
+    assert dll.vorbis_encode_init_vbr(vi, 2, 44100, 0.5) == 0            # shipped class
+    assert (vi.channels, vi.rate, vi.version) == (2, 44100, 0)
+    assert dll.vorbis_info_blocksize(vi, 0) == 256 and dll.vorbis_info_blocksize(vi, 1) == 2048
+    dll.vorbis_info_clear(vi)
+    assert vi.codec_setup is None
+    dll.vorbis_info_init(vi)
+    assert dll.vorbis_encode_init_vbr(vi, 2, 44100, 0.1) == 0            # 0.1f is not 0.1: still the q0.1 pack
+    dll.vorbis_info_clear(vi)
+    assert dll.vorbis_encode_init_vbr(vi, 3, 44100, 0.5) == compat.OV_EIMPL   # no such pack (reference: OV_EIMPL too)
+    assert dll.vorbis_encode_init(vi, 2, 44100, -1, 128000, -1) == 0     # vorbis_encode_init: managed pack
+    assert vi.bitrate_nominal == 128000
+    dll.vorbis_info_clear(vi)
+    assert dll.vorbis_encode_init(vi, 2, 44100, 144000, 128000, 112000) == 0
+    assert (vi.bitrate_upper, vi.bitrate_lower) == (144000, 112000)
+    dll.vorbis_info_clear(vi)
+
+
+def test_comments(dll):
+    vc = compat.VorbisComment()
+    dll.vorbis_comment_init(vc)
+    dll.vorbis_comment_add_tag(vc, b"ENCODER", b"x")
+    dll.vorbis_comment_add_tag(vc, b"title", b"a=b")
+    dll.vorbis_comment_add_tag(vc, b"TITLE", b"second")
+    assert vc.comments == 3 and vc.user_comments[1] == b"title=a=b" and vc.comment_lengths[1] == 9
+    assert dll.vorbis_comment_query_count(vc, b"Title") == 2              # tags compare case-insensitively
+    assert dll.vorbis_comment_query(vc, b"TITLE", 1) == b"second"
+    assert dll.vorbis_comment_query(vc, b"TITLE", 2) is None
+    dll.vorbis_comment_clear(vc)
+    assert vc.comments == 0
+
+
+def test_no_cpu_path_behind_the_entry_points(dll):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    vi, vd = compat.VorbisInfo(), compat.VorbisDspState()
+    dll.vorbis_info_init(vi)
+    assert dll.vorbis_encode_init_vbr(vi, 2, 44100, 0.5) == 0
+    assert dll.vorbis_analysis_init(vd, vi) != 0          # nonzero = failure, as lib/block.c:306-344
+    assert vd.backend_state is None
+    # calls on a stream that never started are refused, not emulated
+    vb, op = compat.VorbisBlock(), compat.OggPacket()
+    assert dll.vorbis_analysis_wrote(vd, 16) == compat.OV_EINVAL
+    assert dll.vorbis_analysis_blockout(vd, vb) == 0
+    assert dll.vorbis_analysis(vb, None) == compat.OV_EINVAL
+    assert dll.vorbis_bitrate_flushpacket(vd, op) == 0
+    dll.vorbis_info_clear(vi)

@@ -66,6 +66,9 @@ SIGNATURES = {
     "vbm_frontend_max_buffered": (C.c_int, [C.c_void_p]),
     "vbm_frontend_capacity": (C.c_int, [C.c_void_p]),
     "vbm_frontend_encode_round": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]),
+    "vbm_frontend_encode_round_streams": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                    C.POINTER(C.c_int), C.c_void_p]),
+    "vbm_packets_compact": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vbm_frontend_encode_rounds": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p]),
     "vbm_analysis_round_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -61,6 +61,7 @@ struct vbm_encoder {
     uint8_t *h_flags[2] = {nullptr, nullptr};
     hipEvent_t ev_stage[2] = {nullptr, nullptr};
     int stage_turn = 0;
+    std::vector<uint8_t> seen;   // [S] scratch of the duplicate check
     std::vector<int> last_ids[kMaxWS];
     std::vector<uint8_t> last_flags[kMaxWS];
     // optional per-stage timing (HIP events on the stream each kernel is launched on)
@@ -565,6 +566,12 @@ extern "C" int vbm_analysis_batch2(vbm_encoder *e, int block_mode, int nsb, cons
     // at all when the caller repeats the previous lists (the steady state of a streaming encode)
     if ((int)e->last_ids[w].size() != nsb || memcmp(e->last_ids[w].data(), stream_ids, nsb * sizeof(int)) ||
         memcmp(e->last_flags[w].data(), wflags, nsb)) {
+        // a stream once per batch: two blocks of one stream would race on its carried state
+        e->seen.assign(e->S, 0);
+        for (int i = 0; i < nsb; i++) {
+            if (e->seen[stream_ids[i]]) { g_vbm_err = "a stream id appears twice in one batch"; return VBM_EINVAL; }
+            e->seen[stream_ids[i]] = 1;
+        }
         const int t = e->stage_turn;
         e->stage_turn ^= 1;
         (void)hipEventSynchronize(e->ev_stage[t]);   // the copy that last used this buffer has run
@@ -742,8 +749,12 @@ static int analysis_round_impl(vbm_encoder *e, const int *counts, const int *str
     }
     if (total == 0) return VBM_OK;
     if (total > e->cap || lanes > e->Ls) return VBM_EINVAL;
-    for (int i = 0; i < total; i++)
+    e->seen.assign(e->S, 0);
+    for (int i = 0; i < total; i++) {
         if (stream_ids[i] < 0 || stream_ids[i] >= e->S) return VBM_EINVAL;
+        if (e->seen[stream_ids[i]]) { g_vbm_err = "a stream id appears twice in one round"; return VBM_EINVAL; }
+        e->seen[stream_ids[i]] = 1;
+    }
     int rc = vbm_encoder_set_sub_batches(e, e->nsplit);   // make sure the internal streams exist
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;

@@ -15,6 +15,7 @@
 #include "frontend.h"
 #include "frontend_kernels.h"
 #include "mdct_kernel.h"
+#include "kernels.h"
 #include "vbm_internal.h"
 
 vbm_setup_host *vbm_encoder_setup_host(vbm_encoder *e);
@@ -200,7 +201,6 @@ extern "C" int vbm_frontend_write(vbm_frontend *fe, const float *d_pcm, int vals
     if (!fe || !d_pcm || vals <= 0) return VBM_EINVAL;
     const vbm_setup *s = fe->hs;
     const int bs1 = s->blocksizes[1];
-    if (vals > 2 * bs1) return VBM_EINVAL;
     for (int i = 0; i < fe->S; i++) {
         if (fe->ended[i]) { g_vbm_err = "vbm_frontend_write after vbm_frontend_finish"; return VBM_EINVAL; }
         if (fe->pcm_current[i] + vals > fe->f.cap - 3 * bs1) {   // OV_EINVAL of lib/block.c:540-541
@@ -241,7 +241,6 @@ extern "C" int vbm_frontend_write_streams(vbm_frontend *fe, const int *stream_id
     if (n == 0) return VBM_OK;
     const vbm_setup *s = fe->hs;
     const int bs1 = s->blocksizes[1];
-    if (vals > 2 * bs1) return VBM_EINVAL;
     std::vector<char> seen(fe->S, 0);
     for (int k = 0; k < n; k++) {
         const int i = stream_ids[k];
@@ -430,6 +429,27 @@ extern "C" int vbm_frontend_encode_round(vbm_frontend *fe, uint8_t *d_packets, i
     return round_impl(fe, d_packets, d_packet_bytes, info, nblocks, stream, false);
 }
 
+// One round for the listed streams only: every other stream is left alone (no block, no state change), as if its
+// application had not called vorbis_analysis_blockout yet.
+extern "C" int vbm_frontend_encode_round_streams(vbm_frontend *fe, const int *stream_ids, int n, uint8_t *d_packets,
+                                                 int *d_packet_bytes, vbm_packet_info *info, int *nblocks, void *stream)
+{
+    if (!fe || n < 0 || (n && !stream_ids) || !nblocks) return VBM_EINVAL;
+    *nblocks = 0;
+    if (n == 0) return VBM_OK;
+    memset(fe->h_hold, 1, fe->S);
+    for (int k = 0; k < n; k++) {
+        if (stream_ids[k] < 0 || stream_ids[k] >= fe->S) return VBM_EINVAL;
+        fe->h_hold[stream_ids[k]] = 0;
+    }
+    hipError_t err = hipMemcpyAsync(fe->d_hold, fe->h_hold, fe->S, hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (err != hipSuccess) return vbm_set_hip_error(err, "hipMemcpyAsync(hold mask)");
+    fe->hold_active = true;
+    const int rc = round_impl(fe, d_packets, d_packet_bytes, info, nblocks, stream, false);
+    fe->hold_active = false;
+    return rc;
+}
+
 // Several rounds in one call, joined at the end: a round only waits for the batches of the round before it that
 // its own streams were in, so the short blocks of the streams that need many rounds run beside the long-block
 // batch of the previous round.  Rounds stop when none produced a block, after max_rounds, when fewer than
@@ -498,6 +518,17 @@ extern "C" int vbm_frontend_encode_rounds_lazy(vbm_frontend *fe, int min_rounds,
 {
     return encode_rounds_impl(fe, min_rounds, max_rounds, headroom, d_packets, d_packet_bytes, info, cap_blocks, round_blocks,
                               nrounds, stream, true);
+}
+
+extern "C" int vbm_packets_compact(const uint8_t *d_packets, const int *d_packet_bytes, int n, int max_packet_bytes,
+                                   uint8_t *d_out, long long *d_offsets, void *stream)
+{
+    if (n < 0 || max_packet_bytes <= 0 || (max_packet_bytes & 3)) return VBM_EINVAL;
+    if (n == 0) return VBM_OK;
+    if (!d_packets || !d_packet_bytes || !d_out || !d_offsets) return VBM_EINVAL;
+    if (((uintptr_t)d_packets & 3) || ((uintptr_t)d_out & 3)) return VBM_EINVAL;
+    return vbm_launch_compact(d_packets, d_packet_bytes, n, max_packet_bytes, d_offsets, d_out, (hipStream_t)stream)
+               ? VBM_EHIP : VBM_OK;
 }
 
 extern "C" int vbm_frontend_join(vbm_frontend *fe, void *stream)

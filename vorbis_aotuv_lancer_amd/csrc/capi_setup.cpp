@@ -107,6 +107,11 @@ extern "C" int vbm_setup_table(const vbm_setup_handle *h, const char *name, cons
         memcpy(sc, v, sizeof(sc));
         RET(sc, 12, 'i');
     }
+    if (!strcmp(name, "bitrate")) {   // managed flag + bitrate_manager_info's rates (nominal, lower, upper)
+        static thread_local double sc[4];
+        sc[0] = s->managed; sc[1] = (double)s->bi_avg_rate; sc[2] = (double)s->bi_min_rate; sc[3] = (double)s->bi_max_rate;
+        RET(sc, 4, 'd');
+    }
 #undef RET
     g_vbm_err = std::string("unknown setup table: ") + name;
     return VBM_EINVAL;

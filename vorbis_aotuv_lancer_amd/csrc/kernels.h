@@ -25,5 +25,7 @@ int vbm_launch_pack_residue(const vbm_batch *b, hipStream_t st);  // after both:
 // tiled [col>>6][rows][64] (tile stride `slab` elements) -> block-major dst[col][rows]
 int vbm_launch_untranspose_f32(const float *srcT, float *dst_bm, int rows, size_t slab, int ncols, hipStream_t st);
 int vbm_launch_untranspose_i32(const int *srcT, int *dst_bm, int rows, size_t slab, int ncols, hipStream_t st);
+// packet rows -> one byte run per packet at 4-byte aligned offsets (off[n+1], exclusive scan of the padded lengths)
+int vbm_launch_compact(const uint8_t *rows, const int *len, int n, int maxb, long long *off, uint8_t *out, hipStream_t q);
 int vbm_launch_untranspose_u8(const uint8_t *srcT, uint8_t *dst_bm, int rows, size_t slab, int ncols, hipStream_t st);
 }

@@ -90,7 +90,62 @@ __global__ void k_reset_streams(vbm_stream_state st, const int *__restrict__ ids
     }
 }
 
+// Packet compaction for host consumers: rows of `maxb` bytes with `len[k]` used -> one byte run per packet at
+// 4-byte-aligned offsets.  k_compact_scan: exclusive prefix sum of the padded lengths by one workgroup (the running
+// total is carried from chunk to chunk); off[n] = total.
+__global__ __launch_bounds__(1024) void k_compact_scan(const int *__restrict__ len, int n, long long *__restrict__ off)
+{
+    __shared__ long long s_part[16];
+    __shared__ long long s_carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int k = base + threadIdx.x;
+        int l = k < n ? len[k] : 0;
+        if (l < 0) l = 0;
+        long long v = (l + 3) & ~3, incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            long long t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) s_part[wave] = incl;
+        __syncthreads();
+        long long before = s_carry;
+        for (int w = 0; w < wave; w++) before += s_part[w];
+        if (k < n) off[k] = before + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = before + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) off[n] = s_carry;
+}
+
+// one wavefront per packet, 32-bit words (rows and offsets are 4-byte aligned; the pad bytes of the last word are
+// whatever the row holds there)
+__global__ void k_compact_copy(const uint8_t *__restrict__ rows, const int *__restrict__ len, int n, int maxb,
+                               const long long *__restrict__ off, uint8_t *__restrict__ out)
+{
+    const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (k >= n) return;
+    const int l = len[k];
+    if (l <= 0) return;
+    const uint32_t *src = (const uint32_t *)(rows + (size_t)k * maxb);
+    uint32_t *dst = (uint32_t *)(out + off[k]);
+    for (int w = lane; w < (l + 3) / 4; w += 64) dst[w] = src[w];
+}
+
 }  // namespace
+
+extern "C" int vbm_launch_compact(const uint8_t *rows, const int *len, int n, int maxb, long long *off, uint8_t *out,
+                                  hipStream_t q)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, q, len, n, off);
+    hipLaunchKernelGGL(k_compact_copy, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, q, rows, len, n, maxb, off, out);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 
 extern "C" int vbm_launch_reset_streams(const vbm_stream_state *st, const int *d_ids, int n, long long bm_fill, hipStream_t q)
 {
