@@ -4,19 +4,22 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload = BASELINE.json configs[2]: "1 GPU: full pipe incl. residue VQ on device, 16384 streams,
-q5 coupled stereo" — 16384 concurrent 44.1 kHz stereo q5 streams per GPU, long blocks (2048
-samples), synthetic PCM already resident in HBM, the WHOLE per-block path on the device (window,
-MDCT, FFT, psy, floor fit/encode, couple/quantise, residue VQ, packet assembly).  configs[1]
-("MDCT+psy on device, VQ on host") is not what this implementation does: nothing runs on the
-host, so the configuration that matches the product is configs[2]; it fits one GPU (~6 GB).
-VBM_BENCH_STREAMS=4096 reproduces configs[1]'s stream count.  One "step" = vbm_analysis_batch over one long block of every stream (each step advances
-every stream by 1024 samples = 23.2 ms of audio; consecutive steps feed consecutive overlapping
-blocks so the carried aoTuV state evolves as in a real encode).  Packets stay on the device.
+Workload = BASELINE.json configs[2]: "1 GPU: full pipe incl. residue VQ on device, 16384 streams, q5 coupled
+stereo" — 16384 concurrent 44.1 kHz stereo q5 streams per GPU, the largest single-GPU configuration (configs[1]
+asks for "VQ on host", which this product does not do: nothing runs on the host).
 
-Streams shard across ranks with no data-path collective: weak scaling, every
-rank encodes its own 16384 streams; value = audio seconds encoded by all ranks / max-over-ranks
-wall time = number of streams that could be encoded at 1x realtime.
+`value` is measured FROM RAW PCM: one step = every stream receives 1024 new samples (23.2 ms of audio, resident
+in HBM) through the device front end — PCM intake, envelope search, block switching, block carve-out
+(vbm_frontend_*) — and the blocks that come out go through the whole per-block path (window, MDCT, FFT, psy,
+floor fit/encode, couple/quantise, residue VQ, packet assembly).  The signal is SURVEY.md §8(d)'s: two sines +
+noise + a 200-sample burst every ~1.33 s at a per-stream phase, so ~15 % of the blocks are short ones.
+value = audio seconds ENCODED inside the timed region (summed over the blocks that came out) / wall seconds
+= concurrent streams encodable at 1x realtime.  The per-block path alone (pre-cut long blocks, no front end: the
+§8(a) measurement) is timed in the same run and reported as `per_block_path`.
+
+Streams shard across ranks with no data-path collective: weak scaling, every rank encodes its own
+16384 streams.  The control path (barrier, max-over-ranks time, work sum) is vorbis_aotuv_lancer_amd/shard.py over
+a gloo group: no RCCL anywhere.  --dry-run exercises that control path without a device.
 """
 import argparse
 import json
@@ -24,32 +27,28 @@ import os
 import sys
 import time
 
-if "--from-pcm" in sys.argv:
-    # the four block types of a blockout round run on four internal HIP streams next to the caller's; the ROCm
-    # runtime folds HIP streams onto 4 hardware queues by default, which makes two of them share one
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-    # lazy joins (the back half of a write's long-block batch beside the next write) need a third workspace
-    os.environ.setdefault("VBM_WORKSPACES", "4")
+# the block types of a blockout round run on internal HIP streams next to the caller's; the ROCm runtime folds
+# HIP streams onto 4 hardware queues by default, which makes two of them share one
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# lazy joins (the back half of a write's long-block batch beside the next write) need more than two workspaces
+os.environ.setdefault("VBM_WORKSPACES", "4")
 
 import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-LAZY_JOIN = os.environ.get("VBM_BENCH_LAZY_JOIN", "1") != "0"   # --from-pcm: vbm_frontend_encode_rounds_lazy
-kept = []
+LAZY_JOIN = os.environ.get("VBM_BENCH_LAZY_JOIN", "1") != "0"   # from PCM: vbm_frontend_encode_rounds_lazy
 STREAMS_PER_GPU = int(os.environ.get("VBM_BENCH_STREAMS", "16384"))
 CHANNELS = 2
 RATE = 44100
 QUALITY = 0.5
-N_LONG = 2048
+N_LONG, N_SHORT = 2048, 256
 HOP = N_LONG // 2
-SPLIT = int(os.environ.get("VBM_BENCH_SPLIT", "1"))   # sub-batches per step, one HIP stream each
-TWO_STREAMS = os.environ.get("VBM_BENCH_TWO_STREAMS", "1") != "0"   # vbm_analysis_batch2: front / back half streams
-MAX_ROUNDS = int(os.environ.get("VBM_BENCH_MAX_ROUNDS", "1"))   # --from-pcm: blockout rounds per write before the
+TWO_STREAMS = os.environ.get("VBM_BENCH_TWO_STREAMS", "1") != "0"   # per-block leg: vbm_analysis_batch2
+MIN_ROUNDS = int(os.environ.get("VBM_BENCH_MIN_ROUNDS", "1"))   # from PCM: blockout rounds per write before the
                                                                  # buffers decide (more while one is past half full)
-DISTINCT_STEPS = 8              # PCM for this many consecutive blocks per stream is kept in HBM
+DISTINCT_STEPS = 8              # per-block leg: PCM for this many consecutive blocks per stream is kept in HBM
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 # algorithmic HBM bytes per long channel-block and stage
@@ -70,19 +69,34 @@ STAGE_BYTES = {
 }
 
 
-def synth_blocks(dev, seed):
-    """[DISTINCT_STEPS][streams][ch][N] block-major PCM cut from one continuous signal per stream."""
-    g = torch.Generator(device=dev).manual_seed(seed)
-    S, C = STREAMS_PER_GPU, CHANNELS
-    total = (DISTINCT_STEPS + 1) * HOP
-    t = torch.arange(total, device=dev, dtype=torch.float32) / RATE
-    f1 = 110.0 + 1650.0 * torch.rand((S, 1, 1), generator=g, device=dev)
-    f2 = 2000.0 + 4000.0 * torch.rand((S, 1, 1), generator=g, device=dev)
-    chan = torch.arange(1, C + 1, device=dev, dtype=torch.float32).view(1, C, 1)
-    x = 0.3 * torch.sin(2 * np.pi * f1 * chan * t) + 0.2 * torch.sin(2 * np.pi * f2 * t + chan)
-    x += 0.05 * (2 * torch.rand((S, C, total), generator=g, device=dev) - 1)
-    blocks = [x[:, :, k * HOP:k * HOP + N_LONG].contiguous() for k in range(DISTINCT_STEPS)]
-    return blocks
+def stream_params(torch, dev, lo, hi):
+    """per-stream signal parameters, a function of the GLOBAL stream index only (a stream sounds the same whichever
+    rank encodes it)"""
+    g = torch.Generator(device="cpu").manual_seed(0x9E3779B9)
+    total = hi                                        # draw for [0, hi), keep [lo, hi): index-stable
+    f1 = (110.0 + 1650.0 * torch.rand(total, generator=g))[lo:hi]
+    f2 = (2000.0 + 4000.0 * torch.rand(total, generator=g))[lo:hi]
+    phase = torch.randint(0, RATE // 3, (total,), generator=g)[lo:hi]
+    return (f1.view(-1, 1, 1).to(dev), f2.view(-1, 1, 1).to(dev), phase.view(-1, 1, 1).to(dev))
+
+
+def synth_pcm(torch, dev, params, gen, first, count):
+    """samples [first, first + count) of every stream of this rank: SURVEY.md §8(d) signal, [S][ch][count] float32"""
+    f1, f2, phase = params
+    S = f1.shape[0]
+    pos = torch.arange(first, first + count, device=dev, dtype=torch.int64)
+    t = pos.to(torch.float64) / RATE
+    chan = torch.arange(1, CHANNELS + 1, device=dev, dtype=torch.float32).view(1, CHANNELS, 1)
+    a1 = (2 * np.pi * f1.double() * chan.double() * t).remainder(2 * np.pi).float()
+    a2 = (2 * np.pi * f2.double() * t).remainder(2 * np.pi).float() + chan
+    x = 0.3 * torch.sin(a1) + 0.2 * torch.sin(a2)
+    x += 0.05 * (2 * torch.rand((S, CHANNELS, count), generator=gen, device=dev) - 1)
+    third = RATE // 3
+    p = pos.view(1, 1, -1) + phase
+    burst = ((p // third) % 4 == 3) & ((p % third) < 200)
+    x += torch.where(burst, 0.6 * (2 * torch.rand((S, CHANNELS, count), generator=gen, device=dev) - 1),
+                     torch.zeros((), device=dev))
+    return x.contiguous()
 
 
 def cpu_baseline(seconds_of_audio=600):
@@ -117,7 +131,8 @@ def cpu_baseline(seconds_of_audio=600):
     except (OSError, StopIteration):
         pass
     return {"value": threads * seconds_of_audio / wall,
-            "unit": f"x realtime on {threads} host cores (= streams at 1x; one stream per thread)",
+            "unit": f"x realtime on {threads} host cores (= streams at 1x; one stream per thread); oracle port, "
+                    "not the reference build",
             "cores": threads, "kind": "port",
             "per_core": sum(per_core) / threads, "cpu_model": model, "host_cpus_available": cores,
             "restatement_vs_reference": {"scalar": 0.65, "lancer_sse2": 0.57,
@@ -128,18 +143,45 @@ def cpu_baseline(seconds_of_audio=600):
                       f"each, block switching + envelope search included), oracle/ scalar C, {wall:.1f} s wall"}
 
 
+def roof_of(stage, ms_per_launch, channel_blocks, traffic):
+    alg = STAGE_BYTES[stage] * channel_blocks
+    ach = alg / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
+    return {"kernel": stage, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": ach / HBM_PEAK_GBPS, "traffic": traffic.get(stage),
+            "algorithmic_bytes_per_launch": alg, "channel_blocks_per_launch": channel_blocks, "kernel_ms": ms_per_launch}
+
+
+def load_traffic(ncb):
+    """PMC-measured HBM bytes per launch and stage (tools/gpu_profile.sh -> profiles/pmc_traffic.json): a committed
+    measurement of an earlier run, tagged with the commit it was taken at — never mixed in silently."""
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(tpath):
+        return {}, None
+    tj = json.load(open(tpath))
+    if tj.get("channel_blocks_per_step") != ncb:
+        return {}, None
+    return tj.get("hbm_bytes_per_launch", {}), {"file": "profiles/pmc_traffic.json", "measured_at": tj.get("commit"),
+                                                "mode": tj.get("mode", "per_block_path")}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--from-pcm", action="store_true",
-                    help="time the whole encoder from raw PCM (stream front end: envelope search + block "
-                         "carve-out on the device, SURVEY 8f N1) instead of the per-block path alone")
+    ap.add_argument("--from-pcm", action="store_true", help="(default) value = whole encoder from raw PCM")
+    ap.add_argument("--per-block", action="store_true",
+                    help="value = the per-block path alone on pre-cut long blocks (the §8(a) measurement; no front "
+                         "end, no block switching) — for A/B work on the kernels")
+    ap.add_argument("--only", choices=["pcm", "block"], default=None, help="run one leg only")
     ap.add_argument("--bitrate", type=int, default=0,
                     help="managed-bitrate setup of this nominal rate (vorbis_encode_init, SURVEY 8f N2: all 15 "
                          "packetblobs per block) instead of the q5 VBR setup of the headline metric")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no device: every rank 'encodes' its streams in VBM_BENCH_DRYRUN_MS milliseconds per step "
+                         "(comma list, one entry per rank) — exercises sharding, barrier, max-over-ranks and the "
+                         "aggregate on the gloo control group")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -147,236 +189,247 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world == 1 and args.gpus > 1:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+
+    # control group first, before anything touches the GPU: gloo over TCP on 127.0.0.1, no RCCL
+    from vorbis_aotuv_lancer_amd import shard
+    shard.init_control(rank, world)
+    lo, hi = shard.stream_range(STREAMS_PER_GPU * world, rank, world)     # this rank's global stream ids
+
+    if args.dry_run:
+        ms = [float(x) for x in os.environ.get("VBM_BENCH_DRYRUN_MS", "10").split(",")]
+        my_ms = ms[rank % len(ms)]
+        shard.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            time.sleep(my_ms * 1e-3)
+        shard.barrier()
+        dt_local = time.perf_counter() - t0
+        audio_local = (hi - lo) * HOP / RATE * args.steps
+        dt = shard.max_over_ranks(dt_local)
+        value = shard.aggregate_throughput(audio_local, dt_local)
+        ranges = shard.gather_objects((lo, hi))
+        audio_all = shard.sum_over_ranks(audio_local)          # collectives: every rank calls them
+        if rank == 0:
+            print(json.dumps({"metric": "realtime-stream-equivalents/node (44.1kHz stereo q5) + MDCT HBM GB/s",
+                              "value": value, "unit": "x realtime (dry run: no device work)", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                              "data": "none (dry run)",
+                              "config": {"workload": "dry run of the control path", "stream_ranges": ranges,
+                                         "audio_s_all_ranks": audio_all,
+                                         "control_backend": shard.backend()}}), flush=True)
+        shard.finish()
+        return
+
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the encode path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_
-        dist = dist_
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
     import vorbis_aotuv_lancer_amd as v
 
     setup = v.Setup(CHANNELS, RATE, bitrate=args.bitrate) if args.bitrate else v.Setup(CHANNELS, RATE, QUALITY)
-    blocks = synth_blocks(dev, seed=1234 + rank)      # resident in HBM before timing starts
-    LONG = 3
-    # The 16384 streams of a step are submitted as SPLIT sub-batches, each to its own encoder object
-    # (its share of the stream state + workspace) on its own HIP stream, so the serial stages of one
-    # sub-batch (few wavefronts) overlap with the wide stages of another.
-    per = STREAMS_PER_GPU // SPLIT
-    assert per * SPLIT == STREAMS_PER_GPU
-    encs = [v.Encoder(setup, per) for _ in range(SPLIT)]
-    enc = encs[0]
-    queues = [torch.cuda.Stream(device=dev) for _ in range(SPLIT)] if SPLIT > 1 else [torch.cuda.current_stream()]
-    ids = np.arange(per, dtype=np.int32)
-    wflags = np.full(per, 3, dtype=np.uint8)   # lW = nW = long
-    parts = [[blk[p * per:(p + 1) * per] for blk in blocks] for p in range(SPLIT)]   # contiguous views
-
-    back_queues = [torch.cuda.Stream(device=dev, priority=int(os.environ.get("VBM_BENCH_BACK_PRIORITY", "0")))
-                   for _ in range(SPLIT)]
-    outs = [[(torch.empty((per, enc.max_packet_bytes), dtype=torch.uint8, device=dev),
-              torch.empty((per,), dtype=torch.int32, device=dev)) for _ in range(2)] for _ in range(SPLIT)]
-    fe = None
-    if args.from_pcm:
-        # one continuous signal per stream, cut into 1024-sample writes (23.2 ms of audio per step)
-        assert SPLIT == 1
-        g = torch.Generator(device=dev).manual_seed(99 + rank)
-        nchunks = args.steps + args.warmup
-        t = torch.arange(nchunks * HOP, device=dev, dtype=torch.float32) / RATE
-        f1 = 110.0 + 1650.0 * torch.rand((STREAMS_PER_GPU, 1, 1), generator=g, device=dev)
-        f2 = 2000.0 + 4000.0 * torch.rand((STREAMS_PER_GPU, 1, 1), generator=g, device=dev)
-        chan = torch.arange(1, CHANNELS + 1, device=dev, dtype=torch.float32).view(1, CHANNELS, 1)
-        chunks = []
-        for k in range(nchunks):
-            tk = t[k * HOP:(k + 1) * HOP]
-            x = 0.3 * torch.sin(2 * np.pi * f1 * chan * tk) + 0.2 * torch.sin(2 * np.pi * f2 * tk + chan)
-            x += 0.05 * (2 * torch.rand((STREAMS_PER_GPU, CHANNELS, HOP), generator=g, device=dev) - 1)
-            chunks.append(x.contiguous())
-        fe = v.FrontEnd(enc)
-        round_count = [0, 0]
-
-    def step(k):
-        if fe is not None:
-            # Round policy: a stream inside a run of short blocks has up to 8 blocks per write, each in its
-            # own round, and such rounds hold a handful of blocks.  Two rounds per write keep every stream
-            # ahead of its input on average (a lagging stream gains one block per step); more only while
-            # some buffer is past half of its capacity.
-            trace = os.environ.get("VBM_BENCH_TRACE")
-            if trace:
-                torch.cuda.synchronize(); t_a = time.perf_counter()
-            fe.write(chunks[k])
-            out = None
-            rounds = 0
-            if not trace and os.environ.get("VBM_BENCH_SINGLE_ROUNDS", "0") != "1":
-                # all rounds of the write in one call: a round runs beside the long-block batch of the round before
-                # it (vbm_frontend_encode_rounds), everything joined at the end
-                info, pk_, nb_, counts = fe.encode_rounds(min_rounds=MAX_ROUNDS, max_rounds=16, headroom=HOP, device=dev,
-                                                          lazy=LAZY_JOIN)
-                round_count[0] += len(counts)
-                round_count[1] += len(info)
-                if LAZY_JOIN:      # the outputs of a call are complete after the next one: keep them alive
-                    kept.append((info, pk_, nb_))
-                    del kept[:-3]
-                return (pk_, nb_) if len(info) else None
-            while True:
-                info, pk_, nb_ = fe.encode_round(dev)
-                if trace:
-                    torch.cuda.synchronize(); t_b = time.perf_counter()
-                    print(f"step {k} round {rounds}: {len(info)} blocks, modes "
-                          f"{np.bincount(info['block_mode'], minlength=4).tolist() if len(info) else []}, "
-                          f"{(t_b - t_a) * 1e3:.2f} ms, max_buffered {fe.max_buffered}", file=sys.stderr)
-                    t_a = t_b
-                if len(info) == 0:
-                    break
-                out = (pk_, nb_) if out is None else out
-                rounds += 1
-                round_count[0] += 1
-                round_count[1] += len(info)
-                if rounds >= MAX_ROUNDS and fe.max_buffered + HOP <= fe.capacity // 2:
-                    break
-            return out
-        out = None
-        for p in range(SPLIT):
-            with torch.cuda.stream(queues[p]):
-                if TWO_STREAMS:   # back half of this step beside the front half of the next (vbm_analysis_batch2)
-                    out = encs[p].analysis_batch(LONG, ids, wflags, parts[p][k % DISTINCT_STEPS],
-                                                 back_stream=back_queues[p], out=outs[p][k & 1])
-                else:
-                    out = encs[p].analysis_batch(LONG, ids, wflags, parts[p][k % DISTINCT_STEPS])
-        return out
+    S = hi - lo
+    enc = v.Encoder(setup, S)
+    params = stream_params(torch, dev, lo, hi)
+    ncb = S * CHANNELS
+    traffic, traffic_src = load_traffic(ncb)
+    legs = [args.only] if args.only else ["pcm", "block"]
 
     def barrier():
-        if fe is not None:
-            fe.join()                # lazy joins: everything begun so far
-        if dist is not None:
-            dist.barrier()
+        shard.barrier()
         torch.cuda.synchronize()
 
-    for k in range(args.warmup):
-        step(k)
-    barrier()
-    for each in encs:
-        each.profile_begin(args.steps)  # HIP events between the stage kernels, on the stream each is launched on
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        res = step(args.warmup + k)
-        if res is not None:
-            pk, nb = res
-    barrier()
-    dt = time.perf_counter() - t0
-    stage_ms, calls = enc.profile_end()
-    for other in encs[1:]:
-        other.profile_end()
-    if dist is not None:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    def timed(step, after=None):
+        for k in range(args.warmup):
+            step(k)
+        if after:
+            after()
+        barrier()
+        enc.profile_begin(args.steps)   # HIP events between the stage kernels, on the stream each is launched on
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step(args.warmup + k)
+        if after:
+            after()
+        barrier()
+        dt_local = time.perf_counter() - t0
+        stage_ms, calls = enc.profile_end()
+        return dt_local, stage_ms, calls, enc.profile_blocks
 
-    audio_s_per_step = STREAMS_PER_GPU * HOP / RATE * world
-    value = audio_s_per_step * args.steps / dt
-    ncb = STREAMS_PER_GPU * CHANNELS
-    # the three transform stages are launched once per call on the whole batch, the later stages once
-    # per sub-batch (include/vorbis_mi355x.h, vbm_encoder_set_sub_batches)
-    sub = enc.sub_batches
-    front = ("window_mdct", "window_fft_log", "transpose")
-    launches = {k: max(calls, 1) * SPLIT * (1 if k in front else sub) for k in stage_ms}
-    units = {k: (ncb // SPLIT) // (1 if k in front else sub) for k in stage_ms}   # channel-blocks per launch
-    per_launch_ms = {k: ms / launches[k] for k, ms in stage_ms.items()}
-    per_step_ms = {k: ms / max(calls, 1) for k, ms in stage_ms.items()}       # summed over the launches of a step
-    dominant = max(per_step_ms, key=per_step_ms.get)
+    results = {}
 
-    def roof(stage):
-        ms = per_launch_ms[stage]
-        ach = STAGE_BYTES[stage] * units[stage] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        return {"kernel": stage, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBPS, "traffic": None,
-                "algorithmic_bytes_per_launch": STAGE_BYTES[stage] * units[stage],
-                "channel_blocks_per_launch": units[stage], "kernel_ms": ms}
+    # ---- leg "pcm": the whole encoder from raw PCM (the headline value) -----------------------------------------
+    if "pcm" in legs:
+        fe = v.FrontEnd(enc)
+        gen = torch.Generator(device=dev).manual_seed(99 + lo)
+        nchunks = args.steps + args.warmup
+        chunks = [synth_pcm(torch, dev, params, gen, k * HOP, HOP) for k in range(nchunks)]   # resident in HBM
+        stat = {"rounds": 0, "blocks": 0, "samples": 0, "modes": np.zeros(4, np.int64), "mean_bytes": 0.0}
+        kept = []
+        counting = [False]
 
-    traffic = {}
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):
-        tj = json.load(open(tpath))
-        if tj.get("channel_blocks_per_step") == ncb and tj.get("sub_batches") == sub:
-            traffic = tj.get("hbm_bytes_per_launch", {})
+        def step_pcm(k):
+            fe.write(chunks[k])
+            info, pk_, nb_, counts = fe.encode_rounds(min_rounds=MIN_ROUNDS, max_rounds=16, headroom=HOP, device=dev,
+                                                      lazy=LAZY_JOIN)
+            if counting[0] and len(info):
+                stat["rounds"] += len(counts)
+                stat["blocks"] += len(info)
+                # what a block advances its stream by: the distance between block centres (lib/block.c:745-759)
+                stat["samples"] += int((np.where(info["W"] != 0, N_LONG, N_SHORT) // 4
+                                        + np.where(info["nW"] != 0, N_LONG, N_SHORT) // 4).sum())
+                stat["modes"] += np.bincount(info["block_mode"], minlength=4)
+            kept.append((info, pk_, nb_))     # lazy: the outputs of a call are complete after the next one
+            del kept[:-3]
 
-    # The MDCT kernel on its own (same launch shape as in the pipeline: one long block of every channel),
-    # timed with HIP events inside the library on this stream: the kernel's own HBM rate.  Inside the
-    # pipeline it shares the GPU with the previous step's back half (vbm_analysis_batch2), which is what
-    # stage_ms_per_launch["window_mdct"] shows.
-    mdct_alone_ms = None
-    if not args.from_pcm:
+        def count_from_now():
+            fe.join()
+            counting[0] = True
+
+        # warmup is not counted; the timed region starts with a join so that nothing of it is left pending
+        for k in range(args.warmup):
+            step_pcm(k)
+        count_from_now()
+        barrier()
+        enc.profile_begin(args.steps * 4)
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step_pcm(args.warmup + k)
+        fe.join()
+        barrier()
+        dt_local = time.perf_counter() - t0
+        blocks_prof = int(v.lib.vbm_encoder_profile_blocks(enc._h))
+        stage_ms, calls = enc.profile_end()
+        nb_last = kept[-1][2]
+        stat["mean_bytes"] = float(nb_last.float().mean().item()) if len(nb_last) else 0.0
+        results["pcm"] = dict(dt_local=dt_local, stage_ms=stage_ms, calls=calls, blocks_prof=blocks_prof, stat=stat,
+                              audio_local=stat["samples"] / RATE)
+        fe.close()
+        del chunks, kept
+
+    # ---- leg "block": the per-block path alone on pre-cut long blocks (§8a) ---------------------------------------
+    if "block" in legs:
+        enc.reset()
+        gen = torch.Generator(device=dev).manual_seed(1234 + lo)
+        x = synth_pcm(torch, dev, params, gen, 0, (DISTINCT_STEPS + 1) * HOP)
+        blocks = [x[:, :, k * HOP:k * HOP + N_LONG].contiguous() for k in range(DISTINCT_STEPS)]
+        del x
+        ids = np.arange(S, dtype=np.int32)
+        wflags = np.full(S, 3, dtype=np.uint8)   # lW = nW = long
+        back_q = torch.cuda.Stream(device=dev)
+        outs = [(torch.empty((S, enc.max_packet_bytes), dtype=torch.uint8, device=dev),
+                 torch.empty((S,), dtype=torch.int32, device=dev)) for _ in range(2)]
+        last = [None]
+
+        def step_block(k):
+            if TWO_STREAMS:   # back half of this step beside the front half of the next (vbm_analysis_batch2)
+                last[0] = enc.analysis_batch(3, ids, wflags, blocks[k % DISTINCT_STEPS], back_stream=back_q, out=outs[k & 1])
+            else:
+                last[0] = enc.analysis_batch(3, ids, wflags, blocks[k % DISTINCT_STEPS])
+
+        dt_local, stage_ms, calls, blocks_prof = timed(step_block)
+        # The MDCT kernel on its own (same launch shape as in the pipeline: one long block of every channel), timed
+        # with HIP events inside the library on this stream: the kernel's own HBM rate.
         import ctypes as C
-        lk = v.MdctLookup(N_LONG, short_n=256)
-        x = blocks[0].reshape(ncb, N_LONG)
+        lk = v.MdctLookup(N_LONG, short_n=N_SHORT)
+        xb = blocks[0].reshape(ncb, N_LONG)
         y = torch.empty((ncb, N_LONG // 2), device=dev)
         ms = C.c_float()
         st_ = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        v.check(v.lib.vbm_window_mdct_time(lk._h, x.data_ptr(), y.data_ptr(), None, ncb, 3, st_, C.byref(ms)))
-        v.check(v.lib.vbm_window_mdct_time(lk._h, x.data_ptr(), y.data_ptr(), None, ncb, 20, st_, C.byref(ms)))
-        mdct_alone_ms = ms.value / 20
+        v.check(v.lib.vbm_window_mdct_time(lk._h, xb.data_ptr(), y.data_ptr(), None, ncb, 3, st_, C.byref(ms)))
+        v.check(v.lib.vbm_window_mdct_time(lk._h, xb.data_ptr(), y.data_ptr(), None, ncb, 20, st_, C.byref(ms)))
+        results["block"] = dict(dt_local=dt_local, stage_ms=stage_ms, calls=calls, blocks_prof=blocks_prof,
+                                audio_local=S * HOP / RATE * args.steps, mdct_alone_ms=ms.value / 20,
+                                mean_bytes=float(last[0][1].float().mean().item()))
+
+    # ---- reduce over ranks (gloo): max of the time, sum of the work ------------------------------------------------
+    for r in results.values():
+        r["dt"] = shard.max_over_ranks(r["dt_local"])
+        r["value"] = shard.aggregate_throughput(r["audio_local"], r["dt_local"])
 
     if rank == 0:
-        r_dom = roof(dominant)
-        r_dom["traffic"] = traffic.get(dominant)
-        r_mdct = roof("window_mdct")
-        r_mdct["traffic"] = traffic.get("window_mdct")
-        if mdct_alone_ms:
-            r_mdct["in_pipeline_ms"] = r_mdct["kernel_ms"]
-            r_mdct["in_pipeline_frac"] = r_mdct["frac"]
-            r_mdct["kernel_ms"] = mdct_alone_ms
-            r_mdct["achieved"] = r_mdct["algorithmic_bytes_per_launch"] / (mdct_alone_ms * 1e-3) / 1e9
-            r_mdct["frac"] = r_mdct["achieved"] / HBM_PEAK_GBPS
-            r_mdct["note"] = "kernel alone, 20 launches of the step's blocks; in_pipeline_* = beside the previous step's back half"
-        mean_bytes = float(nb.float().mean().item())
+        def stage_view(r):
+            calls = max(r["calls"], 1)
+            per_step = {k: ms_ / args.steps for k, ms_ in r["stage_ms"].items()}
+            per_launch = {k: ms_ / calls for k, ms_ in r["stage_ms"].items()}
+            cb = r["blocks_prof"] * CHANNELS // calls if r["blocks_prof"] else ncb   # channel-blocks per timed launch
+            dominant = max(per_step, key=per_step.get)
+            return per_step, per_launch, cb, dominant
+
+        headline = "block" if (args.per_block or "pcm" not in results) else "pcm"
+        R = results[headline]
+        per_step, per_launch, cb, dominant = stage_view(R)
+        roofline = roof_of(dominant, per_launch[dominant], cb, traffic)
+        if traffic_src:
+            roofline["traffic_source"] = traffic_src
         line = {
             "metric": "realtime-stream-equivalents/node (44.1kHz stereo q5) + MDCT HBM GB/s",
-            "value": value,
+            "value": R["value"],
             "unit": "x realtime (concurrent 44.1 kHz stereo q5 streams encodable at 1x)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step": R["dt"] / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": f"configs[2]: full pipe incl. residue VQ on device, {STREAMS_PER_GPU} streams/GPU x 44.1 kHz "
-                            "coupled stereo q5, long blocks (2048), one block per stream per step, PCM resident "
-                            "in HBM, packets left in HBM",
-                "realtime_factor_at_this_concurrency": (HOP / RATE) / (dt / args.steps),
-                "streams_per_gpu": STREAMS_PER_GPU, "channels": CHANNELS, "blocksize": N_LONG,
-                "channel_blocks_per_step": ncb * world,
-                "stages": list(stage_ms.keys()),
+                            "coupled stereo q5, " +
+                            ("from raw PCM: one 1024-sample write per stream per step through the device front end, "
+                             "long + short blocks as the envelope detector decides; PCM resident in HBM, packets left "
+                             "in HBM" if headline == "pcm" else
+                             "per-block path alone: one pre-cut long block (2048) per stream per step"),
+                "signal": "SURVEY 8(d): 0.3 sin(f1) + 0.2 sin(f2) + 0.05 noise, f1 in [110,1760] Hz, f2 in [2,6] kHz per "
+                          "stream, + 0.6-amplitude 200-sample noise burst every 1.33 s at a per-stream phase",
+                "streams_per_gpu": STREAMS_PER_GPU, "channels": CHANNELS,
+                "from_pcm": headline == "pcm",
+                "block_switching": ("in the timed region: PCM intake, envelope search, block switching and block carve-out "
+                                    "run on the device (vbm_frontend_*)" if headline == "pcm" else
+                                    "not in the timed region (pre-cut long blocks)"),
+                "value_counts": "audio seconds of the blocks encoded inside the timed region, all ranks / max-over-ranks wall",
                 "pipeline_complete": True,
-                "from_pcm": bool(args.from_pcm),
+                "control_backend": shard.backend(),
                 **({"managed_bitrate": args.bitrate,
                     "note": "NOT the headline setup: managed bitrate, 15 packetblobs per block (lib/mapping0.c:1204)"}
                    if args.bitrate else {}),
-                **({"blocks_encoded": round_count[1], "rounds": round_count[0], "max_rounds_per_write": MAX_ROUNDS}
-                   if args.from_pcm else {}),
-                "block_switching": ("in the timed region: PCM intake, envelope search and block carve-out run on the "
-                                    "device (vbm_frontend_*); one 1024-sample write per stream per step"
-                                    if args.from_pcm else
-                                    "not in the timed region (long blocks only; --from-pcm times the stream front "
-                                    "end as well)"),
-                "mean_packet_bytes": mean_bytes,
-                "parallelism": f"stream-shard x{world} (no collective); "
-                               + ("front half (transforms, psychoacoustics) and back half (floor, couple/quantise, "
-                                  "packets) of consecutive steps on two HIP streams (vbm_analysis_batch2)"
-                                  if TWO_STREAMS and not args.from_pcm else "one HIP stream"),
+                "parallelism": f"stream-shard x{world} (no collective, control over gloo)",
             },
-            "roofline": r_dom,
-            "mdct_roofline": r_mdct,
-            "stage_ms_per_launch": per_launch_ms,
-            "stage_ms_per_step": per_step_ms,
-            "sub_batches": sub,
+            "roofline": roofline,
+            "stage_ms_per_step": per_step,
+            "stage_ms_per_launch": per_launch,
         }
+        if "pcm" in results:
+            st = results["pcm"]["stat"]
+            line["config"].update({
+                "blocks_encoded": st["blocks"], "rounds": st["rounds"], "rounds_per_write": st["rounds"] / args.steps,
+                "blocks_by_mode": {"impulse_short": int(st["modes"][0]), "padding_short": int(st["modes"][1]),
+                                   "transition_long": int(st["modes"][2]), "long": int(st["modes"][3])},
+                "short_block_fraction": float(st["modes"][:2].sum() / max(st["blocks"], 1)),
+                "input_audio_s_per_rank": S * HOP / RATE * args.steps,
+                "encoded_audio_s_rank0": results["pcm"]["audio_local"],
+                "mean_packet_bytes_last_call": st["mean_bytes"],
+            })
+        if "block" in results:
+            B = results["block"]
+            bstep, blaunch, bcb, bdom = stage_view(B)
+            line["per_block_path"] = {
+                "ms_per_step": B["dt"] / args.steps * 1e3, "value": B["value"],
+                "note": "per-block path alone (§8a): pre-cut long blocks, front end and block switching NOT in the "
+                        "timed region; two HIP streams (vbm_analysis_batch2)" if TWO_STREAMS else "one HIP stream",
+                "stage_ms_per_step": bstep, "dominant": roof_of(bdom, blaunch[bdom], bcb, traffic),
+                "mean_packet_bytes": B["mean_bytes"],
+            }
+            r_mdct = roof_of("window_mdct", blaunch["window_mdct"], bcb, traffic)
+            r_mdct["in_pipeline_ms"] = r_mdct["kernel_ms"]
+            r_mdct["in_pipeline_frac"] = r_mdct["frac"]
+            r_mdct["kernel_ms"] = B["mdct_alone_ms"]
+            r_mdct["achieved"] = r_mdct["algorithmic_bytes_per_launch"] / (B["mdct_alone_ms"] * 1e-3) / 1e9
+            r_mdct["frac"] = r_mdct["achieved"] / HBM_PEAK_GBPS
+            r_mdct["note"] = "kernel alone, 20 launches of the step's blocks; in_pipeline_* = beside the previous step's back half"
+            line["mdct_roofline"] = r_mdct
         if not args.no_cpu_baseline and world == 1:   # host baseline: rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    shard.finish()
 
 
 if __name__ == "__main__":

@@ -318,6 +318,9 @@ int vbm_ogg_stream_pageout(vbm_ogg_stream *os, int flush, const uint8_t **page, 
  * covered.  The first three stages are launched once per call, the others once per sub-batch. */
 int vbm_encoder_profile_begin(vbm_encoder *enc, int max_calls);
 int vbm_encoder_profile_end(vbm_encoder *enc, float *stage_ms, int *ncalls);
+/* stream-blocks covered by the stage times gathered since vbm_encoder_profile_begin (for a round — vbm_analysis_round*,
+ * the front end — the stages of its largest batch are the ones timed); read before vbm_encoder_profile_end */
+long long vbm_encoder_profile_blocks(const vbm_encoder *enc);
 int vbm_encoder_stage_count(void);
 const char *vbm_encoder_stage_name(int k);
 

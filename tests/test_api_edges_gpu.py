@@ -34,6 +34,7 @@ def test_analysis_batch_argument_errors(cuda):
     assert call(n=9) == VBM_EINVAL                                  # more blocks than the encoder was created for
     assert call(n=0) == 0                                           # empty batch: no-op
     assert call(ids_=np.array([0, 1, 2, 8], np.int32)) == VBM_EINVAL  # stream id out of range
+    assert call(ids_=np.array([0, 1, 2, 1], np.int32)) == VBM_EINVAL  # a stream twice in one batch
     assert call(pcm_ptr=pcm.data_ptr() + 4) == VBM_EINVAL           # PCM must be 16-byte aligned
     assert call(pk_ptr=pk.data_ptr() + 1) == VBM_EINVAL             # packets must be 4-byte aligned
     assert lib.vbm_analysis_batch(None, 3, 4, ids.ctypes.data, fl.ctypes.data, pcm.data_ptr(), pk.data_ptr(),
@@ -49,7 +50,9 @@ def test_frontend_write_errors(cuda):
     fe = v.FrontEnd(enc)
     chunk = torch.zeros((3, 2, 1024), device=cuda)
     assert lib.vbm_frontend_write(fe._h, chunk.data_ptr(), 0, None) == VBM_EINVAL
-    assert lib.vbm_frontend_write(fe._h, chunk.data_ptr(), 5000, None) == VBM_EINVAL     # more than two long blocks at once
+    assert lib.vbm_frontend_write(fe._h, chunk.data_ptr(), fe.capacity, None) == VBM_EINVAL  # can never fit the buffer
+    ids = np.array([1, 1], np.int32)                                # a stream once per call
+    assert lib.vbm_frontend_write_streams(fe._h, ids.ctypes.data, 2, chunk.data_ptr(), 1024, None) == VBM_EINVAL
     # without draining, the buffers fill up: the write that would overrun is refused (lib/block.c:540-541)
     refused = False
     for _ in range(fe.capacity // 1024 + 2):

@@ -2,6 +2,11 @@
 import ctypes as C
 import os
 
+# torch first: it brings its own HIP runtime (torch/lib/libamdhip64.so).  Loaded after it, this library binds to
+# that runtime and shares device, streams and allocations with torch; loaded before it, the process would hold two
+# HIP runtimes and this library's calls would go to one that torch's streams and pointers mean nothing to.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvorbis_mi355x.so")
 
@@ -54,6 +59,7 @@ SIGNATURES = {
     "vbm_encoder_fetch_blob": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vbm_encoder_profile_begin": (C.c_int, [C.c_void_p, C.c_int]),
     "vbm_encoder_profile_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "vbm_encoder_profile_blocks": (C.c_longlong, [C.c_void_p]),
     "vbm_encoder_set_sub_batches": (C.c_int, [C.c_void_p, C.c_int]),
     "vbm_encoder_sub_batches": (C.c_int, [C.c_void_p]),
     "vbm_frontend_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p]),

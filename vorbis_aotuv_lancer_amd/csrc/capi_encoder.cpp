@@ -71,6 +71,7 @@ struct vbm_encoder {
     struct span { int stage; size_t begin, end; };
     std::vector<span> spans;
     int prof_calls = 0, prof_max_calls = 0;
+    long long prof_blocks = 0;        // stream-blocks of the profiled batches (rounds: the largest batch of each)
     // rounds with a deferred join (vbm_analysis_round_begin / _join): completion of every block type's batch
     // per workspace, and the batch each stream was part of in the previous round
     hipEvent_t ev_done[kMaxWS][4] = {};
@@ -97,6 +98,27 @@ static const int kFront = 3;                       // stages launched on the who
 static const int kBack = kNumStages - kFront;      // stages launched per slice
 
 static int round64(int x) { return (x + 63) & ~63; }
+
+// (begin, end) event pair around the launches of one stage, on the stream they go to (profiling only)
+struct stage_scope {
+    vbm_encoder *e;
+    bool on;
+    int stage;
+    hipStream_t q;
+    size_t eb = 0;
+    stage_scope(vbm_encoder *e_, bool on_, int stage_, hipStream_t q_) : e(e_), on(on_), stage(stage_), q(q_)
+    {
+        if (on) { eb = e->events_used++; (void)hipEventRecord(e->events[eb], q); }
+    }
+    ~stage_scope()
+    {
+        if (on) {
+            const size_t ee = e->events_used++;
+            (void)hipEventRecord(e->events[ee], q);
+            e->spans.push_back({stage, eb, ee});
+        }
+    }
+};
 static const int kBigBatch = 1024;   // stream-blocks from which a round's batch counts as big (own stream; front end holds its streams)
 
 template <typename T>
@@ -715,7 +737,7 @@ extern "C" int vbm_analysis_batch2(vbm_encoder *e, int block_mode, int nsb, cons
             }
         }
     }
-    if (prof) e->prof_calls++;
+    if (prof) { e->prof_calls++; e->prof_blocks += nsb; }
 #undef STAGE
 #undef RUN
     return VBM_OK;
@@ -832,6 +854,7 @@ static int analysis_round_impl(vbm_encoder *e, const int *counts, const int *str
     // batch on the calling thread), each on its own HIP stream.
     int dev_id = 0;
     (void)hipGetDevice(&dev_id);
+    const bool prof = e->profiling && e->prof_calls < e->prof_max_calls && e->events_used + 2 * (size_t)kNumStages <= e->events.size();
     auto enqueue_type = [&](const int m) -> int {
         hipError_t err;
         int rc = 0;
@@ -848,19 +871,25 @@ static int analysis_round_impl(vbm_encoder *e, const int *counts, const int *str
         vbm_batch v = slice_of(full, pad[m], counts[m]);
         v.pcm = d_pcm + (size_t)off[m] * e->ch * s->blocksizes[1];
         const int W = v.W;
+        // stage timing covers the round's largest batch (enqueued on the calling thread)
+        const bool pr = prof && m == order[0];
+#define TIMED(k, qq) stage_scope scope_##k(e, pr, k, qq)
         RUN(vbm_launch_spread_flags(&v, q));
-        RUN(vbm_launch_window_mdct(v.pcm, v.mdct_bm, W ? v.wflags_cb : nullptr, vbm_setup_device_ptrs(e->H)->mdct_trig[W],
-                                   vbm_setup_device_ptrs(e->H)->window[W], vbm_setup_device_ptrs(e->H)->window[0], v.N,
-                                   s->blocksizes[0], 1, v.ncb, 0, q));
-        RUN(vbm_launch_window_fft_log(v.pcm, v.logfft_bm, v.local_ampmax, W ? v.wflags_cb : nullptr,
-                                      vbm_setup_device_ptrs(e->H)->fft_wa[W], vbm_setup_device_ptrs(e->H)->window[W],
-                                      vbm_setup_device_ptrs(e->H)->window[0], v.N, s->blocksizes[0], v.ncb, q));
-        RUN(vbm_launch_transpose_in(&v, q));
-        RUN(vbm_launch_prologue(&v, q));
-        RUN(vbm_launch_noisemask(&v, q));
-        RUN(vbm_launch_tonemask(&v, q));
-        if (s->managed) RUN(managed_front(v, q));
-        else { RUN(vbm_launch_mix(&v, q)); RUN(vbm_launch_block_state(&v, q)); }
+        { TIMED(0, q);
+          RUN(vbm_launch_window_mdct(v.pcm, v.mdct_bm, W ? v.wflags_cb : nullptr, vbm_setup_device_ptrs(e->H)->mdct_trig[W],
+                                     vbm_setup_device_ptrs(e->H)->window[W], vbm_setup_device_ptrs(e->H)->window[0], v.N,
+                                     s->blocksizes[0], 1, v.ncb, 0, q)); }
+        { TIMED(1, q);
+          RUN(vbm_launch_window_fft_log(v.pcm, v.logfft_bm, v.local_ampmax, W ? v.wflags_cb : nullptr,
+                                        vbm_setup_device_ptrs(e->H)->fft_wa[W], vbm_setup_device_ptrs(e->H)->window[W],
+                                        vbm_setup_device_ptrs(e->H)->window[0], v.N, s->blocksizes[0], v.ncb, q)); }
+        { TIMED(2, q); RUN(vbm_launch_transpose_in(&v, q)); }
+        { TIMED(3, q); RUN(vbm_launch_prologue(&v, q)); }
+        { TIMED(4, q); RUN(vbm_launch_noisemask(&v, q)); }
+        { TIMED(5, q); RUN(vbm_launch_tonemask(&v, q)); }
+        { TIMED(6, q);
+          if (s->managed) RUN(managed_front(v, q));
+          else { RUN(vbm_launch_mix(&v, q)); RUN(vbm_launch_block_state(&v, q)); } }
         if (bigb) {   // hand over to the back-half stream of big batches
             if ((err = hipEventRecord(e->ev_bigfront, q)) != hipSuccess ||
                 (err = hipStreamWaitEvent(e->sub[5], e->ev_bigfront, 0)) != hipSuccess)
@@ -868,19 +897,22 @@ static int analysis_round_impl(vbm_encoder *e, const int *counts, const int *str
             q = e->sub[5];
         }
         if (s->managed) {
+            TIMED(10, q);
             RUN(managed_back(v, d_packets ? d_packets + (size_t)off[m] * e->max_packet_bytes : nullptr, q));
         } else {
-        RUN(vbm_launch_floor_fit(&v, q));
-        RUN(vbm_launch_floor_encode(&v, q));
-        RUN(vbm_launch_couple_quantize(&v, q));
-        RUN(vbm_launch_pack(&v, q));
+            { TIMED(7, q); RUN(vbm_launch_floor_fit(&v, q)); }
+            { TIMED(8, q); RUN(vbm_launch_floor_encode(&v, q)); }
+            { TIMED(9, q); RUN(vbm_launch_couple_quantize(&v, q)); }
+            { TIMED(10, q); RUN(vbm_launch_pack(&v, q)); }
         }
-        if (d_packets && !s->managed)
-            RUN(vbm_launch_untranspose_i32((const int *)v.packetT, (int *)(d_packets + (size_t)off[m] * e->max_packet_bytes),
-                                           e->max_packet_bytes / 4, (size_t)(e->max_packet_bytes / 4) * 64, v.nsb, q));
-        if (d_packet_bytes &&
-            (err = hipMemcpyAsync(d_packet_bytes + off[m], v.packet_bytes, v.nsb * sizeof(int), hipMemcpyDeviceToDevice, q)) != hipSuccess)
-            return vbm_set_hip_error(err, "hipMemcpyAsync(packet_bytes)");
+        { TIMED(11, q);
+          if (d_packets && !s->managed)
+              RUN(vbm_launch_untranspose_i32((const int *)v.packetT, (int *)(d_packets + (size_t)off[m] * e->max_packet_bytes),
+                                             e->max_packet_bytes / 4, (size_t)(e->max_packet_bytes / 4) * 64, v.nsb, q));
+          if (d_packet_bytes &&
+              (err = hipMemcpyAsync(d_packet_bytes + off[m], v.packet_bytes, v.nsb * sizeof(int), hipMemcpyDeviceToDevice, q)) != hipSuccess)
+              return vbm_set_hip_error(err, "hipMemcpyAsync(packet_bytes)"); }
+#undef TIMED
         if ((err = hipEventRecord(e->ev_done[w][m], q)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
         return VBM_OK;
     };
@@ -907,6 +939,10 @@ static int analysis_round_impl(vbm_encoder *e, const int *counts, const int *str
         if (workers[m].joinable()) workers[m].join();
     for (int m = 0; m < 4; m++)
         if (rcs[m]) { g_vbm_err = msgs[m]; return rcs[m]; }
+    if (prof) {
+        e->prof_calls++;
+        e->prof_blocks += counts[order[0]];
+    }
 #undef RUN
     for (int m = 0; m < 4; m++) {
         e->round_big[m] = counts[m] >= kBigBatch;
@@ -997,6 +1033,7 @@ extern "C" int vbm_encoder_profile_begin(vbm_encoder *e, int max_calls)
     e->events_used = 0;
     e->spans.clear();
     e->prof_calls = 0;
+    e->prof_blocks = 0;
     e->prof_max_calls = max_calls;
     e->profiling = true;
     return VBM_OK;
@@ -1022,6 +1059,9 @@ extern "C" int vbm_encoder_profile_end(vbm_encoder *e, float *stage_ms, int *nca
     e->prof_calls = 0;
     return VBM_OK;
 }
+
+// stream-blocks the profiled launches covered (a round: its largest batch), summed over the covered calls
+extern "C" long long vbm_encoder_profile_blocks(const vbm_encoder *e) { return e ? e->prof_blocks : 0; }
 
 extern "C" int vbm_encoder_stage_count(void) { return kNumStages; }
 extern "C" const char *vbm_encoder_stage_name(int k) { return (k >= 0 && k < kNumStages) ? kStageNames[k] : ""; }

@@ -133,6 +133,7 @@ class Encoder:
     def profile_end(self):
         """-> ({stage name: total ms}, calls covered)"""
         n = lib.vbm_encoder_stage_count()
+        self.profile_blocks = int(lib.vbm_encoder_profile_blocks(self._h))
         ms = (C.c_float * n)()
         calls = C.c_int()
         check(lib.vbm_encoder_profile_end(self._h, ms, C.byref(calls)), "vbm_encoder_profile_end")
@@ -226,31 +227,46 @@ class FrontEnd:
         """vbm_frontend_join: the current stream waits for everything begun so far (lazy calls included)"""
         check(lib.vbm_frontend_join(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "vbm_frontend_join")
 
-    def encode_rounds(self, min_rounds=1, max_rounds=8, headroom=1024, device=None, lazy=False):
+    def encode_rounds(self, min_rounds=1, max_rounds=8, headroom=1024, device=None, lazy=False, cap_blocks=None):
         """Up to max_rounds blockout rounds in one call (vbm_frontend_encode_rounds: a round runs beside the
         long-block batch of the round before it; everything is joined at the end).  Returns (info records,
-        packets uint8 [n, max_bytes], nbytes int32 [n], blocks per round) over all rounds, in round order."""
+        packets uint8 [n, max_bytes], nbytes int32 [n], blocks per round) over all rounds, in round order.
+
+        The outputs live in a ring of three buffer sets owned by this object (cap_blocks slots each, default
+        nstreams * min(max_rounds, 4): rounds stop when fewer than nstreams slots are left): what a call returns
+        stays valid until the third call after it.  That also covers lazy=True, where the device still writes a
+        call's packets while the next call is being enqueued (vbm_frontend_encode_rounds_lazy): the buffers are
+        never handed back to torch's allocator while work from a non-torch stream is pending on them."""
         dev = device or torch.device("cuda", torch.cuda.current_device())
         S = self.enc.nstreams
-        cap = S * max_rounds
-        if getattr(self, "_multi_cap", 0) < cap or lazy:
-            # lazy: the records of a call stay valid while the next call fills its own
-            self._multi_info = (PacketInfo * cap)()
-            self._multi_view = np.ctypeslib.as_array(self._multi_info)
-            self._multi_cap = cap
-        packets = torch.empty((cap, self.enc.max_packet_bytes), dtype=torch.uint8, device=dev)
-        nbytes = torch.empty((cap,), dtype=torch.int32, device=dev)
+        cap = cap_blocks or S * min(max_rounds, 4)
+        ring = getattr(self, "_ring", None)
+        if ring is None or self._ring_cap < cap or self._ring_dev != dev:
+            if ring is not None:
+                self.join()
+                torch.cuda.synchronize(dev)
+            self._ring = [((PacketInfo * cap)(), torch.empty((cap, self.enc.max_packet_bytes), dtype=torch.uint8, device=dev),
+                           torch.empty((cap,), dtype=torch.int32, device=dev)) for _ in range(3)]
+            self._ring_views = [np.ctypeslib.as_array(r[0]) for r in self._ring]
+            self._ring_cap, self._ring_dev, self._ring_at = cap, dev, 0
+        at = self._ring_at
+        self._ring_at = (at + 1) % 3
+        info, packets, nbytes = self._ring[at]
         per_round = (C.c_int * max_rounds)()
         nr = C.c_int()
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         fn = lib.vbm_frontend_encode_rounds_lazy if lazy else lib.vbm_frontend_encode_rounds
         check(fn(self._h, min_rounds, max_rounds, headroom, packets.data_ptr(), nbytes.data_ptr(),
-                 self._multi_info, cap, per_round, C.byref(nr), st), "vbm_frontend_encode_rounds")
+                 info, cap, per_round, C.byref(nr), st), "vbm_frontend_encode_rounds")
         counts = [per_round[r] for r in range(nr.value)]
         k = sum(counts)
-        return self._multi_view[:k], packets[:k], nbytes[:k], counts
+        return self._ring_views[at][:k], packets[:k], nbytes[:k], counts
 
     def close(self):
         if self._h:
+            if getattr(self, "_ring", None) is not None:      # nothing may still be writing the ring
+                self.join()
+                torch.cuda.synchronize(self._ring_dev)
+                self._ring = None
             lib.vbm_frontend_destroy(self._h)
             self._h = C.c_void_p()
