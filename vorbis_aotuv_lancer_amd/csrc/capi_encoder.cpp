@@ -272,18 +272,16 @@ extern "C" int vbm_encoder_create(vbm_encoder **out, vbm_setup_handle *setup, in
     {
         size_t rows = 0;
         auto take = [&](size_t r) { size_t at = rows; rows += r; return at * 64; };
-        const size_t o_mdct = take(nmax), o_logfft = take(nmax), o_logmdct = take(nmax), o_noise = take(nmax),
+        const size_t o_mdct = take(nmax), o_logmdct = take(nmax), o_noise = take(nmax),
                      o_tone = take(nmax), o_logmask = take(nmax), o_epeak = take(nmax), o_work = take(nmax),
-                     o_npeak = take(nmax / 8 + 1), o_sum = take((size_t)5 * nmax), o_seed = take(e->max_oct),
-                     o_amp = take(e->max_oct), o_pos = take(e->max_oct), o_post = take((size_t)(VBM_VIF_POSIT + 2) * VBM_PACKETBLOBS),
+                     o_npeak = take(nmax / 8 + 1), o_sum = take((size_t)5 * nmax), o_post = take((size_t)(VBM_VIF_POSIT + 2) * VBM_PACKETBLOBS),
                      o_fout = take(VBM_VIF_POSIT + 2), o_iwork = take(nmax), o_ntfix = take(512);
         b.slab_words = rows * 64;
         float *slab;
         A(slab, float, (L / 64) * b.slab_words);
-        b.mdctT = slab + o_mdct; b.logfftT = slab + o_logfft; b.logmdctT = slab + o_logmdct;
+        b.mdctT = slab + o_mdct; b.logmdctT = slab + o_logmdct;
         b.noiseT = slab + o_noise; b.toneT = slab + o_tone; b.logmaskT = slab + o_logmask;
         b.epeakT = slab + o_epeak; b.workT = slab + o_work; b.npeakT = slab + o_npeak; b.sumT = slab + o_sum;
-        b.seedT = slab + o_seed; b.ampstackT = slab + o_amp; b.posstackT = (int *)(slab + o_pos);
         b.postT_blob = (int *)(slab + o_post);
         b.postT = b.postT_blob + (size_t)(VBM_PACKETBLOBS / 2) * (VBM_VIF_POSIT + 2) * 64;
         b.floor_outT = (int *)(slab + o_fout); b.iworkT = (int *)(slab + o_iwork);
@@ -501,9 +499,9 @@ static vbm_batch slice_of(const vbm_batch &f, int sb0, int nsb, uint8_t *d_packe
     v.global_ampmax += sb0; v.packet_bytes += sb0; v.packet_bits += sb0;
     if (v.packet_bytes_blob) { v.packet_bytes_blob += sb0; v.choice += sb0; v.packetT_blob += stl * 64 * (size_t)f.max_packet_bytes; }
     const size_t co = ct * f.slab_words;
-    v.mdctT += co; v.logfftT += co; v.logmdctT += co; v.noiseT += co; v.toneT += co; v.logmaskT += co;
-    v.epeakT += co; v.workT += co; v.npeakT += co; v.sumT += co; v.seedT += co; v.ampstackT += co;
-    v.posstackT += co; v.postT += co; v.postT_blob += co; v.floor_outT += co; v.iworkT += co; v.ntfixT += co;
+    v.mdctT += co; v.logmdctT += co; v.noiseT += co; v.toneT += co; v.logmaskT += co;
+    v.epeakT += co; v.workT += co; v.npeakT += co; v.sumT += co;
+    v.postT += co; v.postT_blob += co; v.floor_outT += co; v.iworkT += co; v.ntfixT += co;
     const size_t so = stl * f.sb_slab_words;
     v.partwordT += so; v.workvqT += so; v.m6defT += so; v.vqlenT += so; v.vqoffT += so;
     v.vqcodeT += stl * f.vq_slab_words;
@@ -657,13 +655,13 @@ extern "C" int vbm_analysis_batch2(vbm_encoder *e, int block_mode, int nsb, cons
             hipStream_t qa = e->aux[part];
             if ((err = hipEventRecord(e->ev_aux_fork[part], q)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
             if ((err = hipStreamWaitEvent(qa, e->ev_aux_fork[part], 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
-            STAGE(5, qa, RUN(vbm_launch_tonemask(&v, qa)));
+            STAGE(5, qa, RUN(vbm_launch_tonemask(&v, s->psy[v.block_mode].total_octave_lines, qa)));
             if ((err = hipEventRecord(e->ev_aux_join[part], qa)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
             STAGE(4, q, RUN(vbm_launch_noisemask(&v, q)));
             if ((err = hipStreamWaitEvent(q, e->ev_aux_join[part], 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
         } else {
             STAGE(4, q, RUN(vbm_launch_noisemask(&v, q)));
-            STAGE(5, q, RUN(vbm_launch_tonemask(&v, q)));
+            STAGE(5, q, RUN(vbm_launch_tonemask(&v, s->psy[v.block_mode].total_octave_lines, q)));
         }
         if (s->managed) STAGE(6, q, RUN(managed_front(v, q)));
         else STAGE(6, q, { RUN(vbm_launch_mix(&v, q)); RUN(vbm_launch_block_state(&v, q)); });
@@ -886,7 +884,7 @@ static int analysis_round_impl(vbm_encoder *e, const int *counts, const int *str
         { TIMED(2, q); RUN(vbm_launch_transpose_in(&v, q)); }
         { TIMED(3, q); RUN(vbm_launch_prologue(&v, q)); }
         { TIMED(4, q); RUN(vbm_launch_noisemask(&v, q)); }
-        { TIMED(5, q); RUN(vbm_launch_tonemask(&v, q)); }
+        { TIMED(5, q); RUN(vbm_launch_tonemask(&v, s->psy[v.block_mode].total_octave_lines, q)); }
         { TIMED(6, q);
           if (s->managed) RUN(managed_front(v, q));
           else { RUN(vbm_launch_mix(&v, q)); RUN(vbm_launch_block_state(&v, q)); } }

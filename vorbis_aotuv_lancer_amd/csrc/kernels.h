@@ -4,10 +4,10 @@
 #include "batch.h"
 
 extern "C" {
-int vbm_launch_transpose_in(const vbm_batch *b, hipStream_t st);   // mdct_bm/logfft_bm -> mdctT/logfftT
+int vbm_launch_transpose_in(const vbm_batch *b, hipStream_t st);   // mdct_bm -> mdctT
 int vbm_launch_prologue(const vbm_batch *b, hipStream_t st);
 int vbm_launch_noisemask(const vbm_batch *b, hipStream_t st);
-int vbm_launch_tonemask(const vbm_batch *b, hipStream_t st);
+int vbm_launch_tonemask(const vbm_batch *b, int total_octave_lines, hipStream_t st);   // tone_kernels.hip
 int vbm_launch_mix(const vbm_batch *b, hipStream_t st);
 int vbm_mix_can_make_qf(const vbm_batch *b);
 int vbm_launch_reset_streams(const vbm_stream_state *st, const int *d_ids, int n, long long bm_fill, hipStream_t q);

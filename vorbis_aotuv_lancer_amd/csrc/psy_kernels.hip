@@ -8,8 +8,7 @@
 //   k_noisemask   logmdct (lib/mapping0.c:936-950), lb_loudnoise_fix (lib/psy.c:5152-5180),
 //                 _vp_noisemask (lib/psy.c:3770-4074) = bark_noise_hybridmp x2 (:3480-3638),
 //                 ntfix (:3645-3768), compander, M2 post-echo, M8, M9
-//   k_tonemask    _vp_tonemask (lib/psy.c:4076-4142): seed_loop/seed_curve (:652-771),
-//                 max_seeds/seed_chase (:773-1085)
+//   (_vp_tonemask lives in tone_kernels.hip: a workgroup per group of blocks, seeds in LDS)
 //   k_mix         _vp_offset_and_mix (lib/psy.c:4274-4502, set_m3p :4148-4272): offset_select 1 for VBR,
 //                 1 / 2 / 0 with bit_managed for managed bitrate, including the aoTuV carried buffers
 //                 lastmdct / tempmdct
@@ -598,260 +597,7 @@ __global__ void k_nm_post(vbm_batch b, int nchunks)
 
 }
 
-// ---------------------------------------------------------------------------------------------
-// _vp_tonemask in four launches:
-//   k_tm_init    seed[] = NEGINF                                            (sliced over seed lines)
-//   k_tm_stamp   seed_loop: every group of bins stamps its masking curve into seed[] with a
-//                maximum.  max is order-free, so groups are sliced over blockIdx.y and the stamp is
-//                an integer atomicMax on an order-preserving key of the float.
-//   k_tm_chase   max_seeds part 1 = seed_chase (lib/psy.c:773-934): a data-driven stack walk, serial
-//                per lane; the two stack entries the walk looks at live in registers.
-//   k_tm_apply   max_seeds part 2: per bin, the minimum of its seed-line segment raises the ATH
-//                floor (segments precomputed by the host: vbm_psy.seg_p0/seg_p1).  Sliced over bins.
-__device__ __forceinline__ int seed_key(float f)
-{
-    int v = __float_as_int(f);
-    return v ^ ((v >> 31) & 0x7fffffff);   // monotone float -> int (involution)
-}
-__device__ __forceinline__ float seed_val(int k) { return __int_as_float(k ^ ((k >> 31) & 0x7fffffff)); }
-
-__global__ void k_tm_init(vbm_batch b, int nchunks)
-{
-    const int lane = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lane >= b.ncb) return;
-    const size_t tb = TB(b, lane);
-    const vbm_psy *p = psy_of(b);
-    const int tn = p->total_octave_lines;
-    const int c0 = (int)((long)tn * blockIdx.y / nchunks), c1 = (int)((long)tn * (blockIdx.y + 1) / nchunks);
-    int *seed = (int *)b.seedT;
-    const int k = seed_key(NEGINF);
-    for (int i = c0; i < c1; i++) T(seed, i) = k;
-}
-
-__global__ void k_tm_stamp(vbm_batch b, int nchunks)
-{
-    const int lane = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lane >= b.ncb) return;
-    const size_t tb = TB(b, lane);
-    const vbm_psy *p = psy_of(b);
-    const int sb = lane / b.ch;
-    int *seed = (int *)b.seedT;
-    const float *f = b.logfftT;
-    const int g0 = (int)((long)p->ngroups * blockIdx.y / nchunks), g1 = (int)((long)p->ngroups * (blockIdx.y + 1) / nchunks);
-
-    const float global_specmax = b.global_ampmax[sb];
-    const float local_specmax = b.local_ampmax[lane];
-    float att = local_specmax + p->ath_adjatt;
-    if (att < p->ath_maxatt) att = p->ath_maxatt;
-    const float dBoffset = p->max_curve_dB - global_specmax;
-    const int tn = p->total_octave_lines, linesper = p->eighth_octave_lines;
-    const int *__restrict__ group_start = p->group_start, *__restrict__ octave = p->octave;
-    const float *__restrict__ ath = p->ath, *__restrict__ tonecurves = p->tonecurves;
-    const int shiftoc = p->shiftoc, firstoc = p->firstoc;
-
-    // seed_loop (lib/psy.c:719-771), seed_curve (:652-717)
-    for (int g = g0; g < g1; g++) {
-        const int s0 = group_start[g], s1 = group_start[g + 1];
-        float max = T(f, s0);
-        for (int i = s0 + 1; i < s1; i++) {
-            float v = T(f, i);
-            if (v > max) max = v;
-        }
-        const int last = s1 - 1;
-        if (max + 6.f > ath[last] + att) {
-            long oc = octave[last];
-            oc = oc >> shiftoc;
-            if (oc >= VBM_P_BANDS) oc = VBM_P_BANDS - 1;
-            if (oc < 0) oc = 0;
-            const float *curves = tonecurves + (size_t)oc * VBM_P_LEVELS * (VBM_EHMER_MAX + 2);
-            const int ocl = octave[last] - firstoc;
-            int choice = (int)(((double)(max + dBoffset) - 30.) * (double).1f);   // P_LEVEL_0 = 30. (double)
-            choice = VMAX(choice, 0);
-            choice = VMIN(choice, VBM_P_LEVELS - 1);
-            const float *posts = curves + choice * (VBM_EHMER_MAX + 2);
-            const float *curve = posts + 2;
-            const int post1 = (int)posts[1];
-            int seedptr = (int)((float)ocl + (posts[0] - VBM_EHMER_OFFSET) * linesper - (linesper >> 1));
-            // the curve values are loaded eight at a time ahead of the stamps (measured: issuing the eight
-            // atomics without branches, with no-op stamps for the missing points, is slower — the stamps are
-            // bound by atomic throughput, not by the waits the compiler puts between them)
-            // The seeds' current values are read with the curve values, and the atomic is only issued where
-            // it would raise the seed (they only ever grow, so a stale read costs a redundant atomic, never a
-            // missed one): most stamps of the weaker groups lose against a neighbouring peak.
-            for (int i = (int)posts[0]; i < post1 && seedptr < tn; i += 8) {
-                float cv[8];
-                int cur[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) cv[u] = curve[(i + u < post1) ? i + u : post1 - 1];
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const int sp = seedptr + u * linesper;
-                    cur[u] = T(seed, (sp > 0 && sp < tn) ? sp : 1);
-                }
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    if (i + u < post1 && seedptr < tn) {
-                        const int key = seed_key(max + cv[u]);
-                        if (seedptr > 0 && key > cur[u]) atomicMax(&T(seed, seedptr), key);
-                        seedptr += linesper;
-                    }
-                }
-            }
-        }
-    }
-}
-
-template <int TM_KV>
-__global__ void k_tm_chase(vbm_batch b, int lpw)
-{
-    // `lpw` lanes per wavefront: the walk is latency-bound, fewer lanes per wave = more waves in flight
-    const int lane = blockIdx.x * lpw + threadIdx.x;
-    if ((int)threadIdx.x >= lpw || lane >= b.ncb) return;
-    const size_t tb = TB(b, lane);
-    const vbm_psy *p = psy_of(b);
-    float *seed = b.seedT, *ampstack = b.ampstackT;
-    const int *seedk = (const int *)b.seedT;
-    int *posstack = b.posstackT;
-    const int tn = p->total_octave_lines;
-    const int linesper = p->eighth_octave_lines;
-
-    // seed_chase, lib/psy.c:773-934.  (a1,p1) is the stack top, (a2,p2) the entry below it.  The source's
-    // nested tests collapse to one pop condition: an entry is popped while the stack holds two or more,
-    // the new seed is not below the top, and both top entries lie within `linesper` of i with the top
-    // not above the one below it; then the seed is pushed (stack < 2: pushed directly).
-    float *__restrict__ ampL = ampstack + tb;   // this lane's columns: element k at [k * 64]
-    int *__restrict__ posL = posstack + tb;
-    const int *__restrict__ seedL = seedk + tb;
-    // The top TM_K stack entries live in registers (ra[0], rp[0] = top); a push shifts them down (the
-    // entry falling out is in memory already), a pop shifts them up.  Memory is only read when a run of
-    // pops has used up the register copies: then the next TM_K - 1 levels are fetched together.
-#define TM_K 8
-    int stack = 0, nreg = 0;
-    float ra[TM_K];
-    int rp[TM_K];
-#pragma unroll
-    for (int k = 0; k < TM_K; k++) { ra[k] = 0.f; rp[k] = 0; }
-    // seeds are read TM_KV at a time: every batch has to wait for the stack stores issued since the last one
-    // (loads and stores retire in order).  32 for small batches (latency is all that counts: 0.37 -> 0.2 ms),
-    // 8 for full ones (fewer registers; beside the other kernels the larger batches were slightly slower)
-    for (int i = 0; i < tn; i += TM_KV) {
-        int kv[TM_KV];
-#pragma unroll
-        for (int u = 0; u < TM_KV; u++) kv[u] = seedL[(unsigned)((i + u < tn) ? i + u : tn - 1) << 6];
-#pragma unroll
-        for (int u = 0; u < TM_KV; u++) {
-            const int ii = i + u;
-            if (ii < tn) {
-                const float v = seed_val(kv[u]);
-                while (stack >= 2 && !(v < ra[0]) && ii < rp[0] + linesper && ra[0] <= ra[1] && ii < rp[1] + linesper) {
-                    stack--;
-                    nreg--;
-#pragma unroll
-                    for (int k = 0; k < TM_K - 1; k++) { ra[k] = ra[k + 1]; rp[k] = rp[k + 1]; }
-                    if (nreg < 2 && stack >= 2) {
-                        // registers hold level 0 only: fetch levels 1 .. TM_K-1 (entries stack-2, stack-3, ...)
-#pragma unroll
-                        for (int k = 1; k < TM_K; k++) {
-                            const int e = stack - 1 - k;
-                            if (e >= 0) {
-                                ra[k] = ampL[(unsigned)e << 6];
-                                rp[k] = posL[(unsigned)e << 6];
-                            }
-                        }
-                        nreg = stack < TM_K ? stack : TM_K;
-                    }
-                }
-                posL[(unsigned)stack << 6] = ii;
-                ampL[(unsigned)stack << 6] = v;
-                stack++;
-#pragma unroll
-                for (int k = TM_K - 1; k > 0; k--) { ra[k] = ra[k - 1]; rp[k] = rp[k - 1]; }
-                ra[0] = v; rp[0] = ii;
-                if (nreg < TM_K) nreg++;
-            }
-        }
-    }
-#undef TM_K
-
-    // the fill (lib/psy.c:1012-1026): entry e covers seed lines [pos, endpos(e)); the entry rows are the
-    // same for every lane, so eight entries are loaded ahead of the dependent walk
-    {
-        float *__restrict__ seedF = seed + tb;
-        int pos = 0;
-        for (int e0 = 0; e0 < stack; e0 += 8) {
-            float am[9];
-            int ps[9];
-#pragma unroll
-            for (int u = 0; u < 9; u++) {
-                const int e = (e0 + u < stack) ? e0 + u : stack - 1;
-                am[u] = ampL[(unsigned)e << 6];
-                ps[u] = posL[(unsigned)e << 6];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int e = e0 + u;
-                if (e < stack) {
-                    int endpos;
-                    if (e < stack - 1 && am[u + 1] > am[u]) endpos = ps[u + 1];
-                    else endpos = ps[u] + linesper + 1;
-                    if (endpos > tn) endpos = tn;
-                    for (; pos < endpos; pos++) seedF[(unsigned)pos << 6] = am[u];
-                }
-            }
-        }
-    }
-}
-
-__global__ void k_tm_apply(vbm_batch b, int nchunks)
-{
-    const int lane = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lane >= b.ncb) return;
-    const size_t tb = TB(b, lane);
-    const vbm_psy *p = psy_of(b);
-    const int n = p->n;
-    const int c0 = (int)((long)n * blockIdx.y / nchunks), c1 = (int)((long)n * (blockIdx.y + 1) / nchunks);
-    const float *seed = b.seedT;
-    float *flr = b.toneT;
-    const int tn = p->total_octave_lines;
-
-    float att = b.local_ampmax[lane] + p->ath_adjatt;
-    if (att < p->ath_maxatt) att = p->ath_maxatt;
-    const int *__restrict__ seg_p0 = p->seg_p0, *__restrict__ seg_p1 = p->seg_p1;
-    const float *__restrict__ ath = p->ath;
-    const float tone_abs_limit = p->tone_abs_limit;
-
-    int q0 = -2, q1 = -2;
-    float minV = 0.f;
-    // eight bins' values first, then their stores: the seed loads of a bin do not queue behind the store of the
-    // bin before it (loads and stores retire in order)
-    for (int i = c0; i < c1; i += 8) {
-        float out[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int ii = (i + u < c1) ? i + u : c1 - 1;
-            const int p0 = seg_p0[ii], p1 = seg_p1[ii];
-            if (p0 != q0 || p1 != q1) {
-                q0 = p0; q1 = p1;
-                if (p0 < 0) {
-                    minV = T(seed, tn - 1);
-                } else {
-                    minV = T(seed, p0);
-                    if (minV > tone_abs_limit) minV = tone_abs_limit;
-                    for (int pos = p0 + 1; pos <= p1; pos++) {
-                        float sv = T(seed, pos);
-                        if ((sv > NEGINF && sv < minV) || minV == NEGINF) minV = sv;
-                    }
-                }
-            }
-            float v = ath[ii] + att;
-            if (v < minV) v = minV;
-            out[u] = v;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++)
-            if (i + u < c1) T(flr, i + u) = out[u];
-    }
-}
+// (_vp_tonemask: tone_kernels.hip)
 
 // ---------------------------------------------------------------------------------------------
 struct mod3 {
@@ -1269,23 +1015,6 @@ extern "C" int vbm_launch_noisemask(const vbm_batch *b, hipStream_t st)
     hipLaunchKernelGGL(k_nm_solve<2>, dim3(tiles, (unsigned)nchunks), dim3(64), 0, st, *b, nchunks);
     if (b->block_mode <= 2) hipLaunchKernelGGL(k_nm_ntfix, dim3(tiles), dim3(64), 0, st, *b);
     hipLaunchKernelGGL(k_nm_post, dim3(tiles, (unsigned)nchunks), dim3(64), 0, st, *b, nchunks);
-    return hipGetLastError() == hipSuccess ? 0 : -2;
-}
-extern "C" int vbm_launch_tonemask(const vbm_batch *b, hipStream_t st)
-{
-    const unsigned tiles = (unsigned)((b->ncb + 63) / 64);
-    const int nchunks = bin_chunks(b);
-    hipLaunchKernelGGL(k_tm_init, dim3(tiles, (unsigned)nchunks), dim3(64), 0, st, *b, nchunks);
-    hipLaunchKernelGGL(k_tm_stamp, dim3(tiles, (unsigned)nchunks), dim3(64), 0, st, *b, nchunks);
-    static int lpw = 0;
-    if (!lpw) {
-        const char *e = getenv("VBM_CHASE_LPW");   // tuning knob
-        lpw = e ? atoi(e) : 64;
-        if (lpw < 1 || lpw > 64) lpw = 64;
-    }
-    if (b->ncb <= 1024) hipLaunchKernelGGL(k_tm_chase<32>, dim3((unsigned)((b->ncb + lpw - 1) / lpw)), dim3(64), 0, st, *b, lpw);
-    else hipLaunchKernelGGL(k_tm_chase<8>, dim3((unsigned)((b->ncb + lpw - 1) / lpw)), dim3(64), 0, st, *b, lpw);
-    hipLaunchKernelGGL(k_tm_apply, dim3(tiles, (unsigned)nchunks), dim3(64), 0, st, *b, nchunks);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 static const size_t kMixTempBytes = (size_t)256 * 64 * sizeof(float);   // impulse blocks: tempmdct columns in LDS

@@ -54,6 +54,7 @@ struct vbm_psy {                 // vorbis_info_psy + vorbis_look_psy
     // table-only loop structure of _vp_tonemask, unrolled by the host so the device can slice it:
     int ngroups;                     // runs of equal octave[] (the inner while of seed_loop, lib/psy.c:737-743)
     const int *group_start;          // ngroups+1 bins, last = n
+    const int *group_tab;            // ngroups x {first bin, end bin, ath[last] as bits, octave[last]}: 16-byte records (k_tonemask)
     const int *seg_p0, *seg_p1;      // n each: seed lines [p0..p1] whose minimum max_seeds applies to the bin
                                      //   (lib/psy.c:1045-1076); p0 = -1 for the bins of the final tail (:1078-1084)
 };

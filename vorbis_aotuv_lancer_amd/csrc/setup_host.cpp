@@ -180,7 +180,7 @@ void tone_curves(const float *ATH, const float *tonemasks /*[17][6][56]*/, std::
 
 struct PsyTables {
     std::vector<float> tonecurves, ath, ntfix, noiseoffset[VBM_P_NOISECURVES];
-    std::vector<int> octave, bark_lo, bark_hi, group_start, seg_p0, seg_p1;
+    std::vector<int> octave, bark_lo, bark_hi, group_start, seg_p0, seg_p1, group_tab;
 };
 
 // lib/psy.c:352-507
@@ -451,6 +451,7 @@ static void rebase_setup(vbm_setup &s, const unsigned char *base)
         rebase(p.bark_lo, base);
         rebase(p.bark_hi, base);
         rebase(p.group_start, base);
+        rebase(p.group_tab, base);
         rebase(p.seg_p0, base);
         rebase(p.seg_p1, base);
         rebase(p.ntfix_noiseoffset, base);
@@ -669,6 +670,17 @@ vbm_setup_host *vbm_setup_host_load(const char *common_path, const char *mode_pa
             p.bark_lo = as_off<int>(A.put(t.bark_lo));
             p.bark_hi = as_off<int>(A.put(t.bark_hi));
             p.ntfix_noiseoffset = as_off<float>(A.put(t.ntfix));
+            // one 16-byte record per run of equal octave[]: first bin, end bin, ath[last] (bits), octave[last]
+            for (int g = 0; g < p.ngroups; g++) {
+                const int last = t.group_start[g + 1] - 1;
+                int bits;
+                memcpy(&bits, &t.ath[last], 4);
+                t.group_tab.push_back(t.group_start[g]);
+                t.group_tab.push_back(t.group_start[g + 1]);
+                t.group_tab.push_back(bits);
+                t.group_tab.push_back(t.octave[last]);
+            }
+            p.group_tab = as_off<int>(A.put(t.group_tab));
             p.group_start = as_off<int>(A.put(t.group_start));
             p.seg_p0 = as_off<int>(A.put(t.seg_p0));
             p.seg_p1 = as_off<int>(A.put(t.seg_p1));

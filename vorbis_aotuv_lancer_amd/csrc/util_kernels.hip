@@ -163,9 +163,8 @@ extern "C" int vbm_launch_spread_flags(const vbm_batch *b, hipStream_t st)
 
 extern "C" int vbm_launch_transpose_in(const vbm_batch *b, hipStream_t st)
 {
-    int rc = to_tiled<float>(b->mdct_bm, b->mdctT, b->ncb, b->n, b->slab_words, st);
-    if (rc) return rc;
-    return to_tiled<float>(b->logfft_bm, b->logfftT, b->ncb, b->n, b->slab_words, st);
+    // (the log spectrum stays block-major: its only reader, k_tonemask, takes whole rows)
+    return to_tiled<float>(b->mdct_bm, b->mdctT, b->ncb, b->n, b->slab_words, st);
 }
 
 extern "C" int vbm_launch_untranspose_f32(const float *srcT, float *dst_bm, int rows, size_t slab, int ncols,
