@@ -75,15 +75,23 @@ struct vbm_encoder {
     // rounds with a deferred join (vbm_analysis_round_begin / _join): completion of every block type's batch
     // per workspace, and the batch each stream was part of in the previous round
     hipEvent_t ev_done[kMaxWS][4] = {};
-    bool done_pending[kMaxWS][4] = {};
-    std::vector<signed char> round_type;   // [S] block type of the stream's batch in the last round, -1 none
-    bool round_big[4] = {false, false, false, false};   // ... and whether that batch ran on the big-batch stream
+    bool done_pending[kMaxWS][4] = {};     // outputs not yet joined to a caller's stream (vbm_analysis_round_join*)
+    bool reuse_pending[kMaxWS][4] = {};    // the workspace slot has not been waited for by a fork stream since it ran
+    // Order of a stream's blocks across rounds: every batch records an event after its front half (everything
+    // that reads or writes the carried stream state; managed bitrate: after the whole batch, the reservoirs move
+    // in the back half) and every stream remembers the batch it was last part of.  A later batch waits for the
+    // front events of the batches its own streams come from — nothing else orders rounds against each other, so
+    // which HIP stream a round is forked from, or joined to, does not matter.
+    hipEvent_t ev_state[kMaxWS][4] = {};
+    unsigned epoch[kMaxWS][4] = {};        // bumped every time the slot runs a batch
+    signed char slot_queue[kMaxWS][4] = {};// internal HIP stream its front half ran on (sub[] index)
+    struct last_batch { signed char w, m; unsigned epoch; };
+    std::vector<last_batch> last;          // [S] w = -1: none
     // A big batch runs its front half (up to offset_and_mix: everything that touches the carried stream state)
     // on sub[4] and its back half on sub[5], like the two streams of vbm_analysis_batch2: with a lazy join
     // (vbm_analysis_round_join_lazy) the back half of one write's big batch runs beside the front half of the next.
-    hipEvent_t ev_bigfront = nullptr;
     int lazy_w = -1, lazy_m = -1;   // the newest big batch (the one a lazy join leaves pending)
-    int round_w = -1;                      // workspace of that round
+    int round_w = -1;                      // workspace of the newest round
     // the tone-mask branch of a slice runs on its own stream beside the noise-mask branch
     bool overlap_branches = true;
     std::vector<hipStream_t> aux;
@@ -145,10 +153,10 @@ extern "C" void vbm_encoder_destroy(vbm_encoder *e)
     for (hipEvent_t ev : e->ev_aux_fork) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : e->ev_aux_join) (void)hipEventDestroy(ev);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
-    if (e->ev_bigfront) (void)hipEventDestroy(e->ev_bigfront);
     for (int i = 0; i < kMaxWS; i++)
         for (int m = 0; m < 4; m++)
-            if (e->ev_done[i][m]) (void)hipEventDestroy(e->ev_done[i][m]);
+            { if (e->ev_done[i][m]) (void)hipEventDestroy(e->ev_done[i][m]);
+              if (e->ev_state[i][m]) (void)hipEventDestroy(e->ev_state[i][m]); }
     for (int i = 0; i < kMaxWS; i++) {
         if (e->ev_front[i]) (void)hipEventDestroy(e->ev_front[i]);
         if (e->ev_back[i]) (void)hipEventDestroy(e->ev_back[i]);
@@ -349,11 +357,12 @@ extern "C" int vbm_encoder_create(vbm_encoder **out, vbm_setup_handle *setup, in
     }
     for (int i = 0; i < kMaxWS; i++)
         for (int m = 0; m < 4; m++)
-            if (hipEventCreateWithFlags(&e->ev_done[i][m], hipEventDisableTiming) != hipSuccess) {
+            if (hipEventCreateWithFlags(&e->ev_done[i][m], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&e->ev_state[i][m], hipEventDisableTiming) != hipSuccess) {
                 vbm_encoder_destroy(e);
                 return VBM_EHIP;
             }
-    e->round_type.assign(nstreams, -1);
+    e->last.assign(nstreams, {-1, -1, 0u});
     {
         const char *env = getenv("VBM_SUB_BATCHES");
         int rc2 = vbm_encoder_set_sub_batches(e, env ? atoi(env) : 1);
@@ -406,6 +415,16 @@ extern "C" int vbm_encoder_max_packet_bytes(const vbm_encoder *e) { return e ? e
 extern "C" int vbm_encoder_reset(vbm_encoder *e)
 {
     if (!e) return VBM_EINVAL;
+    // Rounds and back halves may still be in flight on the internal (non-blocking) HIP streams, which the null
+    // stream of the copies below does not order against: wait for the device, then forget the bookkeeping.
+    hipError_t serr = hipDeviceSynchronize();
+    if (serr != hipSuccess) return vbm_set_hip_error(serr, "hipDeviceSynchronize");
+    memset(e->done_pending, 0, sizeof(e->done_pending));
+    memset(e->reuse_pending, 0, sizeof(e->reuse_pending));
+    memset(e->back_pending, 0, sizeof(e->back_pending));
+    e->last.assign(e->S, {-1, -1, 0u});
+    e->lazy_w = e->lazy_m = e->round_w = -1;
+    for (int i = 0; i < kMaxWS; i++) { e->last_ids[i].clear(); e->last_flags[i].clear(); }
     vbm_stream_state &st = e->bw[0].st;
     (void)hipMemset(st.mblock, 0, (size_t)(st.Lc / 64) * st.slab_words * sizeof(float));   // mblock + tblock
     (void)hipMemset(st.lowcomp, 0, (size_t)st.Lc * sizeof(float));
@@ -424,6 +443,12 @@ int vbm_encoder_reset_streams_dev(vbm_encoder *e, const int *d_ids, int n, hipSt
     const vbm_setup *s = e->hs;
     const long long fill = s->managed ? (long long)((double)s->bi_reservoir_bits * s->bi_reservoir_bias) : 0;
     if (vbm_analysis_round_join(e, q)) return VBM_EHIP;
+    for (int w = 0; w < e->nws; w++)      // ... including batches a join to another stream has already released
+        for (int m = 0; m < 4; m++)
+            if (e->reuse_pending[w][m]) {
+                if (hipStreamWaitEvent(q, e->ev_done[w][m], 0) != hipSuccess) return VBM_EHIP;
+                e->reuse_pending[w][m] = false;
+            }
     return vbm_launch_reset_streams(&e->bw[0].st, d_ids, n, fill, q) ? VBM_EHIP : VBM_OK;
 }
 
@@ -572,6 +597,13 @@ extern "C" int vbm_analysis_batch2(vbm_encoder *e, int block_mode, int nsb, cons
     {   // rounds begun with a deferred join are completed first: their streams may be in this batch
         int rcj = vbm_analysis_round_join(e, stream);
         if (rcj) return rcj;
+        for (int ww = 0; ww < e->nws; ww++)
+            for (int m = 0; m < 4; m++)
+                if (e->reuse_pending[ww][m]) {
+                    if ((err = hipStreamWaitEvent((hipStream_t)stream, e->ev_done[ww][m], 0)) != hipSuccess)
+                        return vbm_set_hip_error(err, "hipStreamWaitEvent");
+                    e->reuse_pending[ww][m] = false;
+                }
         e->round_w = -1;
     }
     const int w = e->next;
@@ -786,26 +818,23 @@ static int analysis_round_impl(vbm_encoder *e, const int *counts, const int *str
         if ((err = hipStreamWaitEvent(st, e->ev_back[w], 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
         e->back_pending[w] = false;
     }
-    // the round before the previous one used this workspace: all of it has to be done
+    // the round that last used this workspace has to be done before `st` (and everything forked from it) goes on
     for (int m = 0; m < 4; m++)
-        if (e->done_pending[w][m]) {
+        if (e->reuse_pending[w][m]) {
             if ((err = hipStreamWaitEvent(st, e->ev_done[w][m], 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
-            e->done_pending[w][m] = false;
+            e->reuse_pending[w][m] = false;
         }
-    // which batches of the previous round do the streams of each batch of this round come from?
-    bool dep[4][4] = {};
-    const int prev = (w + e->nws - 1) % e->nws;   // workspace of the round before this one
-    if (e->round_w == prev)
-        for (int m = 0; m < 4; m++)
-            for (int i = 0; i < counts[m]; i++) {
-                const int t = e->round_type[stream_ids[off[m] + i]];
-                if (t >= 0) dep[m][t] = true;
-            }
-    if (getenv("VBM_ROUND_DEBUG")) {
-        fprintf(stderr, "round w=%d defer=%d counts=[%d %d %d %d] dep:", w, (int)defer, counts[0], counts[1], counts[2], counts[3]);
-        for (int m = 0; m < 4; m++) fprintf(stderr, " %d<-[%d%d%d%d]", m, dep[m][0], dep[m][1], dep[m][2], dep[m][3]);
-        fprintf(stderr, "\n");
-    }
+    // Which earlier batches do the streams of each batch of this round come from?  bit (ww * 4 + t) of dep[m]:
+    // slot (ww, t) still holds the batch (same epoch) that some stream of batch m was last part of.
+    unsigned dep[4] = {0, 0, 0, 0};
+    for (int m = 0; m < 4; m++)
+        for (int i = 0; i < counts[m]; i++) {
+            const vbm_encoder::last_batch &lb = e->last[stream_ids[off[m] + i]];
+            if (lb.w >= 0 && e->epoch[(int)lb.w][(int)lb.m] == lb.epoch) dep[m] |= 1u << (lb.w * 4 + lb.m);
+        }
+    if (getenv("VBM_ROUND_DEBUG"))
+        fprintf(stderr, "round w=%d defer=%d counts=[%d %d %d %d] dep masks: %04x %04x %04x %04x\n", w, (int)defer, counts[0], counts[1],
+                counts[2], counts[3], dep[0], dep[1], dep[2], dep[3]);
     // ids / flags in the padded lane layout, through the pinned staging (always uploaded: the layout changes
     // from round to round)
     {
@@ -834,7 +863,6 @@ static int analysis_round_impl(vbm_encoder *e, const int *counts, const int *str
     // streams with disjoint CU masks (hipExtStreamCreateWithCUMask) — both slower: the single-wavefront
     // kernels of the small batches run several times slower beside the wide kernels of the big batch, so
     // their chains are better run next to each other than one after another.
-    if (!e->ev_bigfront && hipEventCreateWithFlags(&e->ev_bigfront, hipEventDisableTiming) != hipSuccess) return VBM_EHIP;
     while ((int)e->sub.size() < 6) {      // one per block type + two for a big batch (front / back half)
         hipStream_t q;
         hipEvent_t ev;
@@ -859,11 +887,8 @@ static int analysis_round_impl(vbm_encoder *e, const int *counts, const int *str
         // a big batch gets a stream of its own: the few blocks of its type in the next round must not queue behind it
         const bool bigb = counts[m] >= kBigBatch;
         hipStream_t q = bigb ? e->sub[4] : e->sub[m];
+        const int qid = bigb ? 4 : m;
         if ((err = hipStreamWaitEvent(q, e->ev_fork, 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
-        for (int t = 0; t < 4; t++)
-            if ((t != m || bigb != e->round_big[t]) && dep[m][t] && e->done_pending[prev][t] &&
-                (err = hipStreamWaitEvent(q, e->ev_done[prev][t], 0)) != hipSuccess)
-                return vbm_set_hip_error(err, "hipStreamWaitEvent");
         vbm_batch full;
         configure(e, full, m, counts[m], d_pcm, w);
         vbm_batch v = slice_of(full, pad[m], counts[m]);
@@ -882,15 +907,22 @@ static int analysis_round_impl(vbm_encoder *e, const int *counts, const int *str
                                         vbm_setup_device_ptrs(e->H)->fft_wa[W], vbm_setup_device_ptrs(e->H)->window[W],
                                         vbm_setup_device_ptrs(e->H)->window[0], v.N, s->blocksizes[0], v.ncb, q)); }
         { TIMED(2, q); RUN(vbm_launch_transpose_in(&v, q)); }
+        // the transforms above read the block's PCM only; from here on the carried stream state is involved: the
+        // batches this batch's streams were last part of come first (those on this very HIP stream already do)
+        for (int ww = 0; ww < e->nws; ww++)
+            for (int t = 0; t < 4; t++)
+                if (((dep[m] >> (ww * 4 + t)) & 1u) && (e->slot_queue[ww][t] != qid || s->managed) &&
+                    (err = hipStreamWaitEvent(q, s->managed ? e->ev_done[ww][t] : e->ev_state[ww][t], 0)) != hipSuccess)
+                    return vbm_set_hip_error(err, "hipStreamWaitEvent");
         { TIMED(3, q); RUN(vbm_launch_prologue(&v, q)); }
         { TIMED(4, q); RUN(vbm_launch_noisemask(&v, q)); }
         { TIMED(5, q); RUN(vbm_launch_tonemask(&v, s->psy[v.block_mode].total_octave_lines, q)); }
         { TIMED(6, q);
           if (s->managed) RUN(managed_front(v, q));
           else { RUN(vbm_launch_mix(&v, q)); RUN(vbm_launch_block_state(&v, q)); } }
+        if ((err = hipEventRecord(e->ev_state[w][m], q)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
         if (bigb) {   // hand over to the back-half stream of big batches
-            if ((err = hipEventRecord(e->ev_bigfront, q)) != hipSuccess ||
-                (err = hipStreamWaitEvent(e->sub[5], e->ev_bigfront, 0)) != hipSuccess)
+            if ((err = hipStreamWaitEvent(e->sub[5], e->ev_state[w][m], 0)) != hipSuccess)
                 return vbm_set_hip_error(err, "big batch hand-over");
             q = e->sub[5];
         }
@@ -922,6 +954,8 @@ static int analysis_round_impl(vbm_encoder *e, const int *counts, const int *str
         const int m = order[rank];
         if (!counts[m]) continue;
         e->done_pending[w][m] = true;
+        e->reuse_pending[w][m] = true;
+        e->slot_queue[w][m] = (signed char)(counts[m] >= kBigBatch ? 4 : m);
         if (rank == 0 || !threaded) {
             rcs[m] = enqueue_type(m);
             if (rcs[m]) msgs[m] = g_vbm_err;
@@ -942,14 +976,14 @@ static int analysis_round_impl(vbm_encoder *e, const int *counts, const int *str
         e->prof_blocks += counts[order[0]];
     }
 #undef RUN
-    for (int m = 0; m < 4; m++) {
-        e->round_big[m] = counts[m] >= kBigBatch;
-        if (e->round_big[m]) { e->lazy_w = w; e->lazy_m = m; }
-    }
-    // remember which batch every stream of this round belongs to
-    if (e->round_w >= 0) std::fill(e->round_type.begin(), e->round_type.end(), (signed char)-1);
     for (int m = 0; m < 4; m++)
-        for (int i = 0; i < counts[m]; i++) e->round_type[stream_ids[off[m] + i]] = (signed char)m;
+        if (counts[m] >= kBigBatch) { e->lazy_w = w; e->lazy_m = m; }
+    // remember which batch every stream of this round belongs to
+    for (int m = 0; m < 4; m++) {
+        if (!counts[m]) continue;
+        const unsigned ep = ++e->epoch[w][m];
+        for (int i = 0; i < counts[m]; i++) e->last[stream_ids[off[m] + i]] = {(signed char)w, (signed char)m, ep};
+    }
     e->round_w = w;
     return defer ? VBM_OK : vbm_analysis_round_join(e, stream);
 }
@@ -980,26 +1014,20 @@ extern "C" int vbm_analysis_round_join(vbm_encoder *e, void *stream)
     return VBM_OK;
 }
 
-// like vbm_analysis_round_join, but the newest big batch stays pending: its back half then runs beside the front
-// half of the next write's big batch.  Its outputs are complete on `stream` after the next lazy join (or a join).
+// like vbm_analysis_round_join, but the newest big batch and the batches of the newest round stay pending: a later
+// round's batches wait for the batches their own streams were in (analysis_round_impl), nothing else needs them
+// yet, so the back half of one write's big batch runs beside the front half of the next.  Their outputs are
+// complete on `stream` after the next lazy join (or a join).
 extern "C" int vbm_analysis_round_join_lazy(vbm_encoder *e, void *stream)
 {
     if (!e) return VBM_EINVAL;
     for (int w = 0; w < e->nws; w++)
         for (int m = 0; m < 4; m++)
-            // also left pending: the batches of the last round — the next round's batches wait for the ones their
-            // own streams were in (the dependency tracking of analysis_round_impl), nothing else needs them yet
             if (e->done_pending[w][m] && !(w == e->lazy_w && m == e->lazy_m) && w != e->round_w) {
                 hipError_t err = hipStreamWaitEvent((hipStream_t)stream, e->ev_done[w][m], 0);
                 if (err != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
                 e->done_pending[w][m] = false;
             }
-    // ... but its front half (the part that moves the streams' carried state on) has to be done before anything
-    // enqueued on `stream` later: the next rounds are forked from there
-    if (e->lazy_w >= 0 && e->done_pending[e->lazy_w][e->lazy_m] && e->ev_bigfront) {
-        hipError_t err = hipStreamWaitEvent((hipStream_t)stream, e->ev_bigfront, 0);
-        if (err != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
-    }
     return VBM_OK;
 }
 
@@ -1010,10 +1038,10 @@ extern "C" int vbm_analysis_round_wait_workspace(vbm_encoder *e, void *stream)
     if (!e) return VBM_EINVAL;
     const int w = e->next;
     for (int m = 0; m < 4; m++)
-        if (e->done_pending[w][m]) {
+        if (e->reuse_pending[w][m]) {
             hipError_t err = hipStreamWaitEvent((hipStream_t)stream, e->ev_done[w][m], 0);
             if (err != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
-            e->done_pending[w][m] = false;
+            e->reuse_pending[w][m] = false;
         }
     return VBM_OK;
 }

@@ -40,6 +40,12 @@ struct vbm_frontend {
     int blocks_turn = 0, nblocks_bufs = 2;
     // host mirrors (bounds checking and skipping rounds that cannot produce a block)
     std::vector<int> pcm_current, W, started, ended;
+    // The front end runs on a HIP stream of its own: PCM intake, envelope search, decisions, block gather and the
+    // buffer shift of write k+1 depend on nothing the per-block path of write k does, so they (and the host's
+    // wait for the decisions) overlap it.  A caller's stream is tied in by events: what it produced before a call
+    // is visible to the front end, and it waits for what the call promises (PCM consumed, packets complete).
+    hipStream_t q = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
     bool dirty = false;                   // samples arrived since the envelope was last evaluated
     int pending_steps = 0;                // upper bound of search steps not yet evaluated
 };
@@ -58,6 +64,9 @@ static int fe_alloc(vbm_frontend *fe, T **p, size_t count)
 extern "C" void vbm_frontend_destroy(vbm_frontend *fe)
 {
     if (!fe) return;
+    if (fe->q) { (void)hipStreamSynchronize(fe->q); (void)hipStreamDestroy(fe->q); }
+    if (fe->ev_in) (void)hipEventDestroy(fe->ev_in);
+    if (fe->ev_out) (void)hipEventDestroy(fe->ev_out);
     for (void *p : fe->allocs) (void)hipFree(p);
     if (fe->h_dec) (void)hipHostFree(fe->h_dec);
     if (fe->h_ids) (void)hipHostFree(fe->h_ids);
@@ -65,6 +74,24 @@ extern "C" void vbm_frontend_destroy(vbm_frontend *fe)
     if (fe->h_flags) (void)hipHostFree(fe->h_flags);
     if (fe->h_hold) (void)hipHostFree(fe->h_hold);
     delete fe;
+}
+
+// the front end's stream sees what `stream` has produced so far
+static int fe_enter(vbm_frontend *fe, void *stream)
+{
+    hipError_t err;
+    if ((err = hipEventRecord(fe->ev_in, (hipStream_t)stream)) != hipSuccess ||
+        (err = hipStreamWaitEvent(fe->q, fe->ev_in, 0)) != hipSuccess) return vbm_set_hip_error(err, "front end stream hand-over");
+    return VBM_OK;
+}
+// `stream` waits for what the front end's stream has been given so far
+static int fe_leave(vbm_frontend *fe, void *stream)
+{
+    hipError_t err;
+    if ((err = hipEventRecord(fe->ev_out, fe->q)) != hipSuccess ||
+        (err = hipStreamWaitEvent((hipStream_t)stream, fe->ev_out, 0)) != hipSuccess)
+        return vbm_set_hip_error(err, "front end stream hand-back");
+    return VBM_OK;
 }
 
 extern "C" int vbm_frontend_create(vbm_frontend **out, vbm_encoder *enc)
@@ -131,6 +158,13 @@ extern "C" int vbm_frontend_create(vbm_frontend **out, vbm_encoder *enc)
         g_vbm_err = "hipHostMalloc(front end) failed";
         return VBM_EHIP;
     }
+    if (hipStreamCreateWithFlags(&fe->q, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&fe->ev_in, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&fe->ev_out, hipEventDisableTiming) != hipSuccess) {
+        vbm_frontend_destroy(fe);
+        g_vbm_err = "hipStreamCreate / hipEventCreate (front end) failed";
+        return VBM_EHIP;
+    }
     fe->pcm_current.assign(S, 0);
     fe->W.assign(S, 0);
     fe->started.assign(S, 0);
@@ -148,7 +182,7 @@ extern "C" int vbm_frontend_reset(vbm_frontend *fe)
     const vbm_fe_state &f = fe->f;
     const int S = fe->S, bs1 = fe->hs->blocksizes[1];
     const size_t SC = (size_t)S * fe->ch;
-    hipError_t err = hipSuccess;
+    hipError_t err = hipDeviceSynchronize();   // the front end's own stream and the encoder's rounds: nothing in flight
     auto zero = [&](void *p, size_t bytes) { if (err == hipSuccess) err = hipMemset(p, 0, bytes); };
     zero(f.pcm, (size_t)2 * f.plane * sizeof(float));
     zero(f.parity, S * sizeof(int));
@@ -208,8 +242,16 @@ extern "C" int vbm_frontend_write(vbm_frontend *fe, const float *d_pcm, int vals
             return VBM_EINVAL;
         }
     }
-    hipStream_t st = (hipStream_t)stream;
+    hipStream_t st = fe->q;
+    {
+        int rc = fe_enter(fe, stream);
+        if (rc) return rc;
+    }
     if (vbm_fe_launch_append(&fe->f, d_pcm, vals, s->pre_amplitude, st)) return VBM_EHIP;
+    {   // the caller's buffer is free again once the append has run
+        int rc = fe_leave(fe, stream);
+        if (rc) return rc;
+    }
     bool cross = false;
     for (int i = 0; i < fe->S; i++) {
         fe->pcm_current[i] += vals;
@@ -252,8 +294,10 @@ extern "C" int vbm_frontend_write_streams(vbm_frontend *fe, const int *stream_id
             return VBM_EINVAL;
         }
     }
-    hipStream_t st = (hipStream_t)stream;
-    int rc = upload_ids(fe, stream_ids, n, st);
+    hipStream_t st = fe->q;
+    int rc = fe_enter(fe, stream);
+    if (rc) return rc;
+    rc = upload_ids(fe, stream_ids, n, st);
     if (rc) return rc;
     if (vbm_fe_launch_append_ids(&fe->f, fe->d_ids, n, d_pcm, vals, s->pre_amplitude, st)) return VBM_EHIP;
     bool cross = false;
@@ -275,9 +319,11 @@ extern "C" int vbm_frontend_restart_streams(vbm_frontend *fe, const int *stream_
 {
     if (!fe || n < 0 || (n && !stream_ids)) return VBM_EINVAL;
     if (n == 0) return VBM_OK;
-    hipStream_t st = (hipStream_t)stream;
+    hipStream_t st = fe->q;
     const int bs1 = fe->hs->blocksizes[1];
-    int rc = upload_ids(fe, stream_ids, n, st);
+    int rc = fe_enter(fe, stream);
+    if (rc) return rc;
+    rc = upload_ids(fe, stream_ids, n, st);
     if (rc) return rc;
     if (vbm_fe_launch_restart(&fe->f, fe->d_ids, n, bs1, st)) return VBM_EHIP;
     rc = vbm_encoder_reset_streams_dev(fe->enc, fe->d_ids, n, st);
@@ -302,7 +348,11 @@ extern "C" int vbm_frontend_finish(vbm_frontend *fe, const int *stream_ids, int 
         int s = stream_ids[i];
         if (s < 0 || s >= fe->S || fe->ended[s]) return VBM_EINVAL;
     }
-    hipStream_t st = (hipStream_t)stream;
+    hipStream_t st = fe->q;
+    {
+        int rc = fe_enter(fe, stream);
+        if (rc) return rc;
+    }
     (void)hipStreamSynchronize(st);   // h_ids is reused by the rounds
     memcpy(fe->h_ids, stream_ids, n * sizeof(int));
     hipError_t err = hipMemcpyAsync(fe->d_ids, fe->h_ids, n * sizeof(int), hipMemcpyHostToDevice, st);
@@ -331,8 +381,10 @@ static int round_impl(vbm_frontend *fe, uint8_t *d_packets, int *d_packet_bytes,
     const vbm_setup *ds = vbm_setup_device(fe->H);
     const int S = fe->S, ch = fe->ch;
     const int bs0 = s->blocksizes[0], bs1 = s->blocksizes[1];
-    hipStream_t st = (hipStream_t)stream;
+    hipStream_t st = fe->q;
+    void *const fq = (void *)fe->q;
     hipError_t err;
+    (void)stream;   // the caller's stream is tied in by the entry points around this (fe_enter / joins)
 
     // can any stream have a block?  (host mirrors: the smallest possible block bound is a short
     // next window, lib/block.c:593-600)
@@ -401,7 +453,7 @@ static int round_impl(vbm_frontend *fe, uint8_t *d_packets, int *d_packet_bytes,
 
     // the block buffer of this turn was read by the round before the previous one
     {
-        int rc = vbm_analysis_round_wait_workspace(fe->enc, stream);
+        int rc = vbm_analysis_round_wait_workspace(fe->enc, fq);
         if (rc) return rc;
     }
     float *round_blocks = fe->d_blocks + (size_t)fe->blocks_turn * S * ch * bs1;
@@ -414,9 +466,10 @@ static int round_impl(vbm_frontend *fe, uint8_t *d_packets, int *d_packet_bytes,
             return VBM_EHIP;
     }
     {
-        int rc = defer ? vbm_analysis_round_begin(fe->enc, count, fe->h_ids, fe->h_flags, round_blocks, d_packets, d_packet_bytes, stream)
-                       : vbm_analysis_round(fe->enc, count, fe->h_ids, fe->h_flags, round_blocks, d_packets, d_packet_bytes, stream);
+        // the batches are forked from the front end's stream (behind the gather); the caller's stream joins them
+        int rc = vbm_analysis_round_begin(fe->enc, count, fe->h_ids, fe->h_flags, round_blocks, d_packets, d_packet_bytes, fq);
         if (rc) return rc;
+        if (!defer && (rc = vbm_analysis_round_join(fe->enc, stream))) return rc;
     }
     if (vbm_fe_launch_shift(&fe->f, fe->d_dec, st)) return VBM_EHIP;
     *nblocks = total;
@@ -426,6 +479,9 @@ static int round_impl(vbm_frontend *fe, uint8_t *d_packets, int *d_packet_bytes,
 extern "C" int vbm_frontend_encode_round(vbm_frontend *fe, uint8_t *d_packets, int *d_packet_bytes,
                                          vbm_packet_info *info, int *nblocks, void *stream)
 {
+    if (!fe) return VBM_EINVAL;
+    int rc = fe_enter(fe, stream);
+    if (rc) return rc;
     return round_impl(fe, d_packets, d_packet_bytes, info, nblocks, stream, false);
 }
 
@@ -437,12 +493,16 @@ extern "C" int vbm_frontend_encode_round_streams(vbm_frontend *fe, const int *st
     if (!fe || n < 0 || (n && !stream_ids) || !nblocks) return VBM_EINVAL;
     *nblocks = 0;
     if (n == 0) return VBM_OK;
+    {
+        int rc0 = fe_enter(fe, stream);
+        if (rc0) return rc0;
+    }
     memset(fe->h_hold, 1, fe->S);
     for (int k = 0; k < n; k++) {
         if (stream_ids[k] < 0 || stream_ids[k] >= fe->S) return VBM_EINVAL;
         fe->h_hold[stream_ids[k]] = 0;
     }
-    hipError_t err = hipMemcpyAsync(fe->d_hold, fe->h_hold, fe->S, hipMemcpyHostToDevice, (hipStream_t)stream);
+    hipError_t err = hipMemcpyAsync(fe->d_hold, fe->h_hold, fe->S, hipMemcpyHostToDevice, fe->q);
     if (err != hipSuccess) return vbm_set_hip_error(err, "hipMemcpyAsync(hold mask)");
     fe->hold_active = true;
     const int rc = round_impl(fe, d_packets, d_packet_bytes, info, nblocks, stream, false);
@@ -462,7 +522,8 @@ static int encode_rounds_impl(vbm_frontend *fe, int min_rounds, int max_rounds, 
     if (!fe || !info || !nrounds || max_rounds < 1 || min_rounds < 0 || cap_blocks < 0) return VBM_EINVAL;
     *nrounds = 0;
     const int maxb = vbm_encoder_max_packet_bytes(fe->enc);
-    int done = 0, rc = VBM_OK;
+    int done = 0, rc = fe_enter(fe, stream);
+    if (rc) return rc;
     for (int r = 0; r < max_rounds; r++) {
         if (cap_blocks - done < fe->S) break;
         if (r >= min_rounds && vbm_frontend_max_buffered(fe) + headroom <= vbm_frontend_capacity(fe) / 2) break;
@@ -488,7 +549,7 @@ static int encode_rounds_impl(vbm_frontend *fe, int min_rounds, int max_rounds, 
                     const int sid = info[done + k].stream;
                     if ((info[done + k].block_mode & 3) == big && fe->pcm_current[sid] + headroom <= half) fe->h_hold[sid] = 1;
                 }
-                if (hipMemcpyAsync(fe->d_hold, fe->h_hold, fe->S, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) {
+                if (hipMemcpyAsync(fe->d_hold, fe->h_hold, fe->S, hipMemcpyHostToDevice, fe->q) != hipSuccess) {
                     rc = VBM_EHIP;
                     break;
                 }
