@@ -32,10 +32,13 @@
  *
  * Differences from the reference, all outside the data path:
  *   - vb->pcm is NULL: the block's PCM stays on the device (lib/block.c:653-698 copies it to the arena).
- *   - Carve-ahead: a round carves the next block of every pool stream that has one.  An application
- *     that calls vorbis_analysis_wrote(vd,0) while blocks of earlier writes are still un-asked-for
- *     gets the end-of-stream extrapolation of a drained buffer (the reference would fit it to the
- *     undrained one, lib/block.c:497-537).  vorbis_mi355x_ctl(VORBIS_MI355X_CARVE_AHEAD, 0) turns
+ *   - Carve-ahead: a round carves the next block of every pool stream that has one, not only of the
+ *     asking stream.  Blocks and packets do not depend on when they are carved, with one exception:
+ *     vorbis_analysis_wrote(vd,0) fits the end-of-stream extrapolation to the samples the buffer holds
+ *     at that moment (lib/block.c:497-537).  A stream that drains its blocks before declaring the end
+ *     (examples/encoder_example.c) or declares it before its first blockout (test/write_read.c:95-99)
+ *     is not affected; one that leaves blocks un-asked-for WHILE another stream of the pool triggers
+ *     a round may find them carved already.  vorbis_mi355x_ctl(VORBIS_MI355X_CARVE_AHEAD, 0) turns
  *     carve-ahead off: a round then holds the asking stream only, exactly the reference's order.
  *   - vorbis_encode_init_vbr / vorbis_encode_init pick a SHIPPED mode pack (libvorbisenc's setup code
  *     is out of scope): OV_EIMPL for a (channels, rate, quality) without one.

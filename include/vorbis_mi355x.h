@@ -329,6 +329,9 @@ const char *vbm_encoder_stage_name(int k);
  *   vbm_host_mdct_trig     n + n/4 floats  (mdct_init, lib/mdct.c:67-76)
  *   vbm_host_fft_twiddles  n floats        (drfti1,   lib/smallft.c:5576-5644; = trigcache + n) */
 int vbm_host_mdct_trig(int n, float *out);
+/*   vbm_host_book_lattice  {quantvals, minval, delta} of a maptype-1 codebook header, as vorbis_book_init_encode
+ *                          derives them (lib/sharedbook.c:303-317: _book_maptype1_quantvals, _float32_unpack) */
+int vbm_host_book_lattice(long q_min, long q_delta, long entries, int dim, int *out);
 int vbm_host_fft_twiddles(int n, float *out);
 
 /* Bench helper: time `iters` back-to-back launches of vbm_window_mdct_batch with HIP

@@ -227,6 +227,7 @@ typedef struct orc_setup {
     int managed;
     long bi_avg_rate, bi_min_rate, bi_max_rate, bi_reservoir_bits;
     double bi_reservoir_bias, bi_slew_damp;
+    long bitrate_upper, bitrate_nominal, bitrate_lower; /* vorbis_info fields set by lib/vorbisenc.c:876-884 */
     /* looks built once (lib/block.c:181-303) */
     orc_mdct mdct[2];
     orc_drft fft[2];
@@ -343,6 +344,11 @@ int orc_block_choice(const orc_block *vb, int *blob_bytes /* [ORC_PACKETBLOBS] o
 const unsigned char *orc_block_blob(const orc_block *vb, int k, long *bytes);
 void orc_stream_bitrate_state(const orc_stream *v, int64_t *out /* avg_reservoir, minmax_reservoir */, double *avgfloat);
 void orc_block_info64(const orc_block *vb, int64_t *out); /* granulepos, sequence */
+
+/* the three header packets (vorbis_analysis_headerout, lib/info.c:500-717) packed from this setup: returns the
+ * total length, writes the packets back to back into buf (if cap suffices) and their lengths into lens[3] */
+long orc_header_packets(const orc_setup *s, const char *vendor, const char *const *comments, int ncomments,
+                        unsigned char *buf, long cap, long *lens);
 
 /* survey probe signal + driver: encodes `secs` seconds of the synthetic
  * signal and writes [int32 len][bytes] records to `out_path`; returns the packet count. */

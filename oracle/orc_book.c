@@ -139,7 +139,7 @@ static uint32_t *make_words(const signed char *l, long n)
     return r;
 }
 
-static long maptype1_quantvals(long entries, long dim)
+long orc_maptype1_quantvals(long entries, long dim)
 {
     long vals;
     if (entries < 1) return 0;
@@ -163,7 +163,7 @@ static long maptype1_quantvals(long entries, long dim)
 void orc_book_init_encode(orc_book *c)
 {
     c->codelist = make_words(c->lengthlist, c->entries);
-    c->quantvals = (int)maptype1_quantvals(c->entries, c->dim);
+    c->quantvals = (int)orc_maptype1_quantvals(c->entries, c->dim);
     c->minval = (int)rint(float32_unpack(c->q_min));
     c->delta = (int)rint(float32_unpack(c->q_delta));
 }
@@ -234,3 +234,15 @@ int orc_book_besterror(const orc_book *book, int *a)
         for (i = 0; i < dim; i++) *a++ -= p[i];
     return index;
 }
+
+/* test hook: {quantvals, minval, delta} of a maptype-1 book header (lib/sharedbook.c:303-317) and the unpacked
+ * floats themselves, for the reference's self-test books (lib/sharedbook.c:474-560) */
+void orc_book_lattice(long q_min, long q_delta, long entries, long dim, int *out, float *unpacked)
+{
+    out[0] = (int)orc_maptype1_quantvals(entries, dim);
+    out[1] = (int)rint(float32_unpack(q_min));
+    out[2] = (int)rint(float32_unpack(q_delta));
+    unpacked[0] = float32_unpack(q_min);
+    unpacked[1] = float32_unpack(q_delta);
+}
+

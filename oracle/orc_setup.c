@@ -446,6 +446,12 @@ orc_setup *orc_setup_load(const char *common_vpk, const char *mode_vpk)
     }
     s->pre_amplitude = *(const float *)need(fm, "hi/pre_amplitude", VPK_F32, &n);
     s->managed = *(const int *)need(fm, "info/managed", VPK_I32, &n);
+    {
+        const int64_t *br = (const int64_t *)need(fm, "info/bitrates", VPK_I64, &n);   /* upper, nominal, lower */
+        s->bitrate_upper = (long)br[0];
+        s->bitrate_nominal = (long)br[1];
+        s->bitrate_lower = (long)br[2];
+    }
     if (s->managed) { /* lib/vorbisenc.c:890-901 */
         const int64_t *r = (const int64_t *)need(fm, "bi/rates", VPK_I64, &n);
         const double *d = (const double *)need(fm, "bi/floats", VPK_F64, &n);

@@ -174,17 +174,20 @@ def test_frontend_multi_round_calls_match_oracle(oracle, cuda, max_rounds):
     frontend_vs_oracle(oracle, cuda, 2, 44100, 0.5, NS=200, seconds=1.6, multi=True, max_rounds=max_rounds)
 
 
-def test_frontend_lazy_joins_at_scale(oracle, cuda, monkeypatch):
+@pytest.mark.parametrize("bitrate", [None, (144000, 128000, 112000)])
+def test_frontend_lazy_joins_at_scale(oracle, cuda, monkeypatch, bitrate):
     """vbm_frontend_encode_rounds_lazy with a big batch (>= 1024 long blocks per write): its back half stays
     pending across calls (four workspaces in rotation), outputs are read one call late; 1100 streams carrying
-    5 distinct signals, each compared with the oracle"""
+    5 distinct signals, each compared with the oracle.  With a managed-bitrate setup the back half of a batch
+    moves carried state too (the reservoirs, k_bitrate_choose): a stream's next block — in whatever batch of
+    whatever round it lands — has to wait for it, or the blob choice goes wrong."""
     import vorbis_aotuv_lancer_amd as v
     monkeypatch.setenv("VBM_WORKSPACES", "4")
-    K, S, ch, rate, q = 5, 1100, 2, 44100, 0.5
-    nsamp = 30 * 1024
+    K, S, ch, rate, q = 5, 1100, 2, 44100, (0.5 if bitrate is None else None)
+    nsamp = (30 if bitrate is None else 22) * 1024
     base = [synth_signal(ch, rate, nsamp, seed=640 + k, level=1.0 if k % 2 else 0.05) for k in range(K)]
     sigs = [base[s % K] for s in range(S)]
-    osetup = orc.Setup(oracle, ch, rate, q)
+    osetup = orc.Setup(oracle, ch, rate, q, bitrate=bitrate)
     want = []
     for k in range(K):
         st = orc.Stream(osetup)
@@ -195,7 +198,7 @@ def test_frontend_lazy_joins_at_scale(oracle, cuda, monkeypatch):
             seq.extend(b["packet"] for b in st.blocks())
         st.close()
         want.append(seq)
-    enc = v.Encoder(v.Setup(ch, rate, q), S)
+    enc = v.Encoder(v.Setup(ch, rate, q, bitrate=bitrate), S)
     fe = v.FrontEnd(enc)
     got = [[] for _ in range(S)]
     allp = torch.from_numpy(np.stack(sigs)).to(cuda)

@@ -330,3 +330,44 @@ def test_ogg_pages_round_trip():
         done += ends
         assert pg["granule"] == (gps[done - 1] if ends else -1)
     os_.close()
+
+
+def test_header_bytes_equal_the_oracles(oracle):
+    """The three header packets of every shipped setup, packed by the product from the mode pack
+    (csrc/capi_stream.cpp) and by the oracle from its own setup structs (oracle/orc_headers.c, restating
+    lib/info.c:500-617, lib/codebook.c:158-275, floor1_pack, res0_pack, mapping0_pack): byte for byte."""
+    import ctypes as C
+    import glob
+    import re
+    import vorbis_aotuv_lancer_amd as v
+    from tests import orc
+    lib = oracle.lib
+    lib.orc_header_packets.restype = C.c_long
+    lib.orc_header_packets.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.c_void_p, C.c_long,
+                                       C.POINTER(C.c_long)]
+    comments = ["ENCODER=test", "TITLE=header parity", ""]
+    arr = (C.c_char_p * len(comments))(*[c.encode() for c in comments])
+    packs = sorted(glob.glob(os.path.join(os.path.dirname(v.LIB_PATH), "data", "mode_*.vpk")))
+    assert len(packs) >= 20
+    for path in packs:
+        m = re.match(r"mode_(\d+)ch_(\d+)_(q|b)(-?[\d.]+?)(?:_max(\d+))?(?:_min(\d+))?\.vpk", os.path.basename(path))
+        ch, rate = int(m.group(1)), int(m.group(2))
+        if m.group(3) == "q":
+            kw = dict(q=float(m.group(4)))
+            setup = v.Setup(ch, rate, float(m.group(4)))
+        else:
+            br = (int(m.group(5) or -1), int(m.group(4)), int(m.group(6) or -1))
+            kw = dict(bitrate=br)
+            setup = v.Setup(ch, rate, bitrate=br)
+        mine = v.header_packets(setup, comments)
+        osetup = orc.Setup(oracle, ch, rate, **kw)
+        lens = (C.c_long * 3)()
+        total = lib.orc_header_packets(osetup.h, None, arr, len(comments), None, 0, lens)
+        assert total > 0
+        buf = (C.c_ubyte * total)()
+        assert lib.orc_header_packets(osetup.h, None, arr, len(comments), buf, total, lens) == total
+        raw = bytes(buf)
+        theirs = [raw[:lens[0]], raw[lens[0]:lens[0] + lens[1]], raw[lens[0] + lens[1]:]]
+        for k in range(3):
+            assert mine[k] == theirs[k], (os.path.basename(path), k, len(mine[k]), len(theirs[k]))
+        setup.close()

@@ -94,6 +94,7 @@ SIGNATURES = {
     "vbm_encoder_stage_name": (C.c_char_p, [C.c_int]),
     "vbm_host_mdct_trig": (C.c_int, [C.c_int, C.c_void_p]),
     "vbm_host_fft_twiddles": (C.c_int, [C.c_int, C.c_void_p]),
+    "vbm_host_book_lattice": (C.c_int, [C.c_long, C.c_long, C.c_long, C.c_int, C.POINTER(C.c_int)]),
     "vbm_window_mdct_time": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int,
                                        C.c_void_p, C.POINTER(C.c_float)]),
 }

@@ -299,22 +299,16 @@ int pool_upload(cpool *p, cstream *only)
     }
 }
 
-// vorbis_analysis_wrote(v, 0) for stream s: everything it wrote goes up first; with carve-ahead its blocks are
-// carved before the end is declared (what an application that drains after every write has done by then)
+// vorbis_analysis_wrote(v, 0) for stream s: everything it wrote goes up, then the end is declared on the device at
+// once — blocks the application has not asked for yet stay in the buffer, and the end-of-stream extrapolation is
+// fitted to exactly that buffer, as in the reference (lib/block.c:497-537; its own test writes 2048 samples and
+// declares the end before the first vorbis_analysis_blockout, test/write_read.c:95-99)
 int stream_send_eof(cpool *p, cstream *s)
 {
     int carve;
     { std::lock_guard<std::mutex> lk(g_mu); carve = g_carve_ahead; }
     int rc = pool_upload(p, carve ? nullptr : s);
     if (rc) return rc;
-    if (carve) {
-        for (;;) {
-            bool got = false;
-            rc = pool_round(p, s, false, &got);
-            if (rc) return rc;
-            if (!got) break;
-        }
-    }
     const int id = s->slot;
     rc = vbm_frontend_finish(p->fe, &id, 1, p->q);
     if (rc) return rc;

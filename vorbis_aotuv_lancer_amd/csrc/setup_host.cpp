@@ -427,6 +427,17 @@ float float32_unpack(long val)   // lib/sharedbook.c:66-80
 
 }  // namespace
 
+// encode-side lattice of a maptype-1 book as vorbis_book_init_encode derives it (lib/sharedbook.c:303-317):
+// out = {quantvals, minval, delta}.  Exposed for the CPU parity test on the reference's own self-test books.
+extern "C" int vbm_host_book_lattice(long q_min, long q_delta, long entries, int dim, int *out)
+{
+    if (!out || dim < 1 || entries < 1) return -131;
+    out[0] = quantvals1(entries, dim);
+    out[1] = (int)rint((double)float32_unpack(q_min));
+    out[2] = (int)rint((double)float32_unpack(q_delta));
+    return 0;
+}
+
 struct vbm_setup_host {
     Arena arena;
     vbm_setup s;                    // pointer fields hold (offset+1) until rebased
