@@ -291,6 +291,35 @@ int vbm_frontend_encode_rounds_lazy(vbm_frontend *fe, int min_rounds, int max_ro
                                     int *round_blocks, int *nrounds, void *stream);
 int vbm_frontend_join(vbm_frontend *fe, void *stream);
 
+/* Rounds built on the device: the throughput form of the loop above with NO host in it.  The device decides which
+ * streams deliver a block (k_fe_classify), assigns them lanes (k_fe_plan), carves the blocks and runs the per-block
+ * path on device-resident counts; the call only enqueues work and returns.  Nothing is read back: the host learns
+ * what came out from the outputs, when it chooses to look.
+ *   Layout: a round has vbm_device_round_lanes() output slots ("lanes").  Block type m owns a fixed region of
+ *   them (the impulse, padding and transition blocks a quarter of the stream count each, then the long blocks with
+ *   one lane per stream); inside a region the blocks follow in ascending stream order.  A stream whose type's region is full keeps its block for the next round,
+ *   and the streams of a call's first long-block batch get no further block in that call (rounds may be deferred:
+ *   blocks and packets do not depend on when they run).
+ *   nrounds rounds per call; round r writes
+ *     d_packets      [r][lane][max_packet_bytes]   (may be NULL)
+ *     d_packet_bytes [r][lane]   length, -2 = no block in this lane, -1 = packet outgrew the buffer
+ *     d_info         [r][lane]   vbm_packet_info of the lane's block (stream = -1: none); device or pinned host memory
+ *     d_counts       [r][4]      blocks of each type (device memory: the round's kernels read it while they run)
+ *   all complete on `stream` when the call's work has run (lazy != 0: the long-block batch of the call only after
+ *   the next call or vbm_frontend_join, as vbm_frontend_encode_rounds_lazy).  The buffers belong to the call until then.
+ *   The encoder must have been created with max_batch >= vbm_device_round_lanes(setup, nstreams).
+ * Mixing with the host-built rounds above is allowed (e.g. to drain completely before vbm_frontend_finish): the first
+ * such call waits for the front end's stream and fetches the buffer fills it needs.  While only device-built rounds
+ * run, vbm_frontend_write does not check the buffer fill: the caller keeps rounds and writes in balance (two rounds
+ * per 1024-sample write keep every stream ahead of its input at the block-switching rates of music; the fill can be
+ * watched with vbm_frontend_max_buffered, which synchronises). */
+int vbm_device_round_lanes(const vbm_setup_handle *setup, int nstreams);
+int vbm_frontend_encode_rounds_device(vbm_frontend *fe, int nrounds, uint8_t *d_packets, int *d_packet_bytes,
+                                      vbm_packet_info *d_info, int *d_counts, int lazy, void *stream);
+/* running totals of the device-built rounds: out[0..3] blocks of type 0..3, out[4] samples all streams advanced by
+ * (synchronises the front end's stream) */
+int vbm_frontend_device_stats(vbm_frontend *fe, unsigned long long *out);
+
 /* ---- stream wrapper, host only ------------------------------------------------
  * vbm_header_packets = vorbis_analysis_headerout (reference lib/info.c:636-717): the identification,
  * comment and setup header packets of a setup, concatenated in buf with their sizes in lens[3]

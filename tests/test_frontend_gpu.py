@@ -366,3 +366,86 @@ def test_streams_out_of_lock_step(oracle, cuda):
     for name in sig:
         assert chunk[name] * 1024 == sig[name].shape[1]
         assert logical[name] == oracle_stream(sig[name]), f"stream {name} differs from the oracle"
+
+
+# ---- rounds built on the device (vbm_frontend_encode_rounds_device): no host in the loop ------------------------
+def collect_device(sink, fe, out):
+    """outputs of one encode_rounds_device call (device tensors) -> sink[stream]"""
+    import vorbis_aotuv_lancer_amd as v
+    info, packets, nbytes, counts = out
+    nb = nbytes.cpu().numpy()
+    live = np.flatnonzero(nb != -2)
+    if len(live) == 0:
+        return 0
+    rec = info.cpu().numpy().view(np.dtype(v.PacketInfo))[:, 0]
+    pk = packets[torch.from_numpy(live).to(packets.device)].cpu().numpy()
+    for j, k in enumerate(live):
+        pi = rec[k]
+        assert nb[k] >= 0, "packet buffer overflow"
+        assert pi["stream"] >= 0
+        sink[int(pi["stream"])].append(((int(pi["lW"]), int(pi["W"]), int(pi["nW"]), int(pi["block_mode"]), int(pi["eos"]),
+                                         int(pi["granulepos"]), int(pi["packetno"])), bytes(pk[j, :nb[k]])))
+    # the counts are the live lanes per block type, and every region is filled from its start
+    c = counts.cpu().numpy()
+    assert int(c.sum()) == len(live)
+    return len(live)
+
+
+@pytest.mark.parametrize("ch,rate,q,NS,lazy", [(2, 44100, 0.5, 70, False), (2, 44100, 0.5, 70, True), (2, 44100, 0.5, 1100, False),
+                                               (2, 44100, 0.5, 1100, True), (6, 48000, 0.8, 9, False),
+                                               (1, 8000, 0.5, 6, False), (2, 44100, -0.1, 5, False)])
+def test_device_built_rounds(oracle, cuda, monkeypatch, ch, rate, q, NS, lazy):
+    """Two device-built rounds per 1024-sample write, outputs read one call late when lazy; then the host-built
+    rounds drain what is left and end the streams.  Per stream, in order: block flags, granule positions, packet
+    numbers and packet bytes of the oracle."""
+    import vorbis_aotuv_lancer_amd as v
+    monkeypatch.setenv("VBM_WORKSPACES", "4")
+    K = min(NS, 7)
+    nsamp = 26 * 1024
+    base = [synth_signal(ch, rate, nsamp, seed=730 + k, level=1.0 if k % 3 else 0.05) for k in range(K)]
+    osetup = orc.Setup(oracle, ch, rate, q)
+    want = []
+    for k in range(K):
+        st = orc.Stream(osetup)
+        oracle.lib.orc_stream_set_capture(st.v, 0)
+        seq = []
+        for at in range(0, nsamp, 1024):
+            st.write(base[k][:, at:at + 1024])
+            seq.extend(st.blocks())
+        st.finish()
+        seq.extend(st.blocks())
+        st.close()
+        want.append([((b["lW"], b["W"], b["nW"], b["block_mode"], b["eos"], b["granulepos"], b["sequence"]), b["packet"])
+                     for b in seq])
+    setup = v.Setup(ch, rate, q)
+    lanes = v.lib.vbm_device_round_lanes(setup._h, NS)
+    enc = v.Encoder(setup, NS, max_batch=lanes)
+    fe = v.FrontEnd(enc)
+    assert fe.device_lanes == lanes
+    got = [[] for _ in range(NS)]
+    allp = torch.from_numpy(np.stack([base[s % K] for s in range(NS)])).to(cuda)
+    held = None
+    total = 0
+    for at in range(0, nsamp, 1024):
+        fe.write(allp[:, :, at:at + 1024].contiguous())
+        # (two rounds per write keep up with 256/2048 switching; 512-sample blocks at one size come 4 per write)
+        out = fe.encode_rounds_device(nrounds=2 if setup.blocksizes[0] != setup.blocksizes[1] else 5, lazy=lazy)
+        if lazy:
+            if held is not None:
+                total += collect_device(got, fe, held)
+            held = out
+        else:
+            total += collect_device(got, fe, out)
+    if lazy:
+        fe.join()
+        total += collect_device(got, fe, held)
+    modes, samples = fe.device_stats()
+    assert sum(modes) == total
+    drain(fe, got)                      # host-built rounds take over: the mirrors are fetched from the device
+    fe.finish()
+    drain(fe, got)
+    bad = [(s, k) for s in range(NS) for k, (g, w) in enumerate(zip(got[s], want[s % K])) if g != w]
+    assert not bad, (len(bad), bad[:12], [got[s][k][0] for s, k in bad[:6]])
+    for s in range(NS):
+        assert len(got[s]) == len(want[s % K]), (s, len(got[s]), len(want[s % K]))
+    fe.close()

@@ -84,6 +84,10 @@ SIGNATURES = {
     "vbm_frontend_encode_rounds_lazy": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                   C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p]),
     "vbm_frontend_join": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vbm_device_round_lanes": (C.c_int, [C.c_void_p, C.c_int]),
+    "vbm_frontend_encode_rounds_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                    C.c_int, C.c_void_p]),
+    "vbm_frontend_device_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong)]),
     "vbm_analysis_round_wait_workspace": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vbm_header_packets": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_void_p, C.c_long, C.POINTER(C.c_long)]),
     "vbm_ogg_stream_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),

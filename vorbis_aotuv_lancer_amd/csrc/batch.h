@@ -34,8 +34,10 @@ struct vbm_batch {
     int W;                          // block_mode >> 1
     int N, n;                       // block size, n = N/2
     int ch;
-    int nsb;                        // stream-blocks in this batch
+    int nsb;                        // stream-blocks in this batch (with d_nsb set: the most it may hold = launch bound)
     int ncb;                        // channel-blocks = nsb*ch
+    const int *d_nsb;               // device-resident count of a round built on the device (frontend: k_fe_plan), or NULL:
+                                    //   kernels take vbm_nsb(b) / vbm_ncb(b), launchers size their grids for nsb
     int L;                          // ncb rounded up to 64
     int Ls;                         // nsb rounded up to 64
     const int *stream_id;           // [nsb] stream index of every stream-block
@@ -96,6 +98,8 @@ struct vbm_batch {
 };
 
 #ifdef __HIPCC__
+__device__ __forceinline__ int vbm_nsb(const vbm_batch &b) { return b.d_nsb ? *b.d_nsb : b.nsb; }
+__device__ __forceinline__ int vbm_ncb(const vbm_batch &b) { return vbm_nsb(b) * b.ch; }
 // lib/scales.h:43-51
 __device__ __forceinline__ float vbm_todB(float x)
 {

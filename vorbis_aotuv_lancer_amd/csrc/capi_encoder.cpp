@@ -92,6 +92,8 @@ struct vbm_encoder {
     // (vbm_analysis_round_join_lazy) the back half of one write's big batch runs beside the front half of the next.
     int lazy_w = -1, lazy_m = -1;   // the newest big batch (the one a lazy join leaves pending)
     int round_w = -1;                      // workspace of the newest round
+    int call_big_w = -1;                   // rounds built on the device: workspace of the current call's big batch
+    bool device_rounds = false;            // ... have run: the per-stream bookkeeping below knows nothing of them
     // the tone-mask branch of a slice runs on its own stream beside the noise-mask branch
     bool overlap_branches = true;
     std::vector<hipStream_t> aux;
@@ -671,10 +673,10 @@ extern "C" int vbm_analysis_batch2(vbm_encoder *e, int block_mode, int nsb, cons
     // loop A: window + MDCT, window + FFT + log spectrum (wave per block), whole batch
     STAGE(0, st, RUN(vbm_launch_window_mdct(b.pcm, b.mdct_bm, W ? b.wflags_cb : nullptr,
                                             vbm_setup_device_ptrs(e->H)->mdct_trig[W], vbm_setup_device_ptrs(e->H)->window[W],
-                                            vbm_setup_device_ptrs(e->H)->window[0], b.N, s->blocksizes[0], 1, b.ncb, 0, st)));
+                                            vbm_setup_device_ptrs(e->H)->window[0], b.N, s->blocksizes[0], 1, b.ncb, 0, nullptr, 0, st)));
     STAGE(1, st, RUN(vbm_launch_window_fft_log(b.pcm, b.logfft_bm, b.local_ampmax, W ? b.wflags_cb : nullptr,
                                                vbm_setup_device_ptrs(e->H)->fft_wa[W], vbm_setup_device_ptrs(e->H)->window[W],
-                                               vbm_setup_device_ptrs(e->H)->window[0], b.N, s->blocksizes[0], b.ncb, st)));
+                                               vbm_setup_device_ptrs(e->H)->window[0], b.N, s->blocksizes[0], b.ncb, nullptr, 0, st)));
     STAGE(2, st, RUN(vbm_launch_transpose_in(&b, st)));
 
     // the stages between the transforms and the hand-over: psychoacoustics, offset_and_mix, block state
@@ -773,6 +775,85 @@ extern "C" int vbm_analysis_batch2(vbm_encoder *e, int block_mode, int nsb, cons
     return VBM_OK;
 }
 
+// One block type of a round: its whole pipeline on its internal HIP stream(s), forked from ev_fork.
+struct type_job {
+    int m, w;                    // block type, workspace
+    int lane0, bound;            // first stream-block lane of the type's region; blocks in it (d_nsb set: the most it may hold)
+    const int *d_nsb;            // device-resident count (rounds built on the device) or NULL
+    const float *pcm;            // the region's block PCM [bound][ch][N]
+    uint8_t *d_packets;          // outputs of this type, already offset (may be NULL)
+    int *d_packet_bytes;
+    bool big, timed;
+    unsigned depmask;            // bit (ww * 4 + t): slot (ww, t) holds a batch this one's streams may come from
+};
+
+static int enqueue_job(vbm_encoder *e, const type_job &j)
+{
+    const vbm_setup *s = e->hs;
+    hipError_t err;
+    int rc = 0;
+    const int m = j.m, w = j.w;
+    hipStream_t q = j.big ? e->sub[4] : e->sub[m];
+    const int qid = j.big ? 4 : m;
+    if ((err = hipStreamWaitEvent(q, e->ev_fork, 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
+    vbm_batch full;
+    configure(e, full, m, j.bound, j.pcm, w);
+    vbm_batch v = slice_of(full, j.lane0, j.bound);
+    v.pcm = j.pcm;
+    v.d_nsb = j.d_nsb;
+    const int W = v.W;
+    const bool pr = j.timed;
+#define RUN(x) do { rc = (x); if (rc) { g_vbm_err = std::string("launch failed: ") + #x; return VBM_EHIP; } } while (0)
+#define TIMED(k, qq) stage_scope scope_##k(e, pr, k, qq)
+    RUN(vbm_launch_spread_flags(&v, q));
+    { TIMED(0, q);
+      RUN(vbm_launch_window_mdct(v.pcm, v.mdct_bm, W ? v.wflags_cb : nullptr, vbm_setup_device_ptrs(e->H)->mdct_trig[W],
+                                 vbm_setup_device_ptrs(e->H)->window[W], vbm_setup_device_ptrs(e->H)->window[0], v.N,
+                                 s->blocksizes[0], 1, v.ncb, 0, v.d_nsb, e->ch, q)); }
+    { TIMED(1, q);
+      RUN(vbm_launch_window_fft_log(v.pcm, v.logfft_bm, v.local_ampmax, W ? v.wflags_cb : nullptr,
+                                    vbm_setup_device_ptrs(e->H)->fft_wa[W], vbm_setup_device_ptrs(e->H)->window[W],
+                                    vbm_setup_device_ptrs(e->H)->window[0], v.N, s->blocksizes[0], v.ncb, v.d_nsb, e->ch, q)); }
+    { TIMED(2, q); RUN(vbm_launch_transpose_in(&v, q)); }
+    // the transforms above read the block's PCM only; from here on the carried stream state is involved: the
+    // batches this batch's streams were last part of come first (those on this very HIP stream already do)
+    for (int ww = 0; ww < e->nws; ww++)
+        for (int t = 0; t < 4; t++)
+            if (((j.depmask >> (ww * 4 + t)) & 1u) && (e->slot_queue[ww][t] != qid || s->managed) &&
+                (err = hipStreamWaitEvent(q, s->managed ? e->ev_done[ww][t] : e->ev_state[ww][t], 0)) != hipSuccess)
+                return vbm_set_hip_error(err, "hipStreamWaitEvent");
+    { TIMED(3, q); RUN(vbm_launch_prologue(&v, q)); }
+    { TIMED(4, q); RUN(vbm_launch_noisemask(&v, q)); }
+    { TIMED(5, q); RUN(vbm_launch_tonemask(&v, s->psy[v.block_mode].total_octave_lines, q)); }
+    { TIMED(6, q);
+      if (s->managed) RUN(managed_front(v, q));
+      else { RUN(vbm_launch_mix(&v, q)); RUN(vbm_launch_block_state(&v, q)); } }
+    if ((err = hipEventRecord(e->ev_state[w][m], q)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
+    if (j.big) {   // hand over to the back-half stream of big batches
+        if ((err = hipStreamWaitEvent(e->sub[5], e->ev_state[w][m], 0)) != hipSuccess)
+            return vbm_set_hip_error(err, "big batch hand-over");
+        q = e->sub[5];
+    }
+    if (s->managed) {
+        TIMED(10, q);
+        RUN(managed_back(v, j.d_packets, q));
+    } else {
+        { TIMED(7, q); RUN(vbm_launch_floor_fit(&v, q)); }
+        { TIMED(8, q); RUN(vbm_launch_floor_encode(&v, q)); }
+        { TIMED(9, q); RUN(vbm_launch_couple_quantize(&v, q)); }
+        { TIMED(10, q); RUN(vbm_launch_pack(&v, q)); }
+    }
+    { TIMED(11, q);
+      if (j.d_packets && !s->managed)
+          RUN(vbm_launch_untranspose_counted((const int *)v.packetT, (int *)j.d_packets, e->max_packet_bytes / 4,
+                                             (size_t)(e->max_packet_bytes / 4) * 64, v.nsb, v.d_nsb, q));
+      if (j.d_packet_bytes) RUN(vbm_launch_copy_counted(j.d_packet_bytes, v.packet_bytes, v.nsb, v.d_nsb, q)); }
+#undef TIMED
+#undef RUN
+    if ((err = hipEventRecord(e->ev_done[w][m], q)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
+    return VBM_OK;
+}
+
 // One round of blocks of all four block types: counts[m] blocks of type m, described by stream_ids /
 // wflags grouped by type (type 0 first); d_pcm: the blocks of type m start at float offset
 // (blocks of lower types) * channels * blocksizes[1] and lie block-major [count][channels][N_m].
@@ -824,6 +905,15 @@ static int analysis_round_impl(vbm_encoder *e, const int *counts, const int *str
             if ((err = hipStreamWaitEvent(st, e->ev_done[w][m], 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
             e->reuse_pending[w][m] = false;
         }
+    if (e->device_rounds) {   // rounds built on the device ran in between: their streams are unknown here
+        for (int ww = 0; ww < e->nws; ww++)
+            for (int t = 0; t < 4; t++)
+                if (e->reuse_pending[ww][t]) {
+                    if ((err = hipStreamWaitEvent(st, e->ev_done[ww][t], 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
+                    e->reuse_pending[ww][t] = false;
+                }
+        e->device_rounds = false;
+    }
     // Which earlier batches do the streams of each batch of this round come from?  bit (ww * 4 + t) of dep[m]:
     // slot (ww, t) still holds the batch (same epoch) that some stream of batch m was last part of.
     unsigned dep[4] = {0, 0, 0, 0};
@@ -882,69 +972,15 @@ static int analysis_round_impl(vbm_encoder *e, const int *counts, const int *str
     (void)hipGetDevice(&dev_id);
     const bool prof = e->profiling && e->prof_calls < e->prof_max_calls && e->events_used + 2 * (size_t)kNumStages <= e->events.size();
     auto enqueue_type = [&](const int m) -> int {
-        hipError_t err;
-        int rc = 0;
-        // a big batch gets a stream of its own: the few blocks of its type in the next round must not queue behind it
-        const bool bigb = counts[m] >= kBigBatch;
-        hipStream_t q = bigb ? e->sub[4] : e->sub[m];
-        const int qid = bigb ? 4 : m;
-        if ((err = hipStreamWaitEvent(q, e->ev_fork, 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
-        vbm_batch full;
-        configure(e, full, m, counts[m], d_pcm, w);
-        vbm_batch v = slice_of(full, pad[m], counts[m]);
-        v.pcm = d_pcm + (size_t)off[m] * e->ch * s->blocksizes[1];
-        const int W = v.W;
-        // stage timing covers the round's largest batch (enqueued on the calling thread)
-        const bool pr = prof && m == order[0];
-#define TIMED(k, qq) stage_scope scope_##k(e, pr, k, qq)
-        RUN(vbm_launch_spread_flags(&v, q));
-        { TIMED(0, q);
-          RUN(vbm_launch_window_mdct(v.pcm, v.mdct_bm, W ? v.wflags_cb : nullptr, vbm_setup_device_ptrs(e->H)->mdct_trig[W],
-                                     vbm_setup_device_ptrs(e->H)->window[W], vbm_setup_device_ptrs(e->H)->window[0], v.N,
-                                     s->blocksizes[0], 1, v.ncb, 0, q)); }
-        { TIMED(1, q);
-          RUN(vbm_launch_window_fft_log(v.pcm, v.logfft_bm, v.local_ampmax, W ? v.wflags_cb : nullptr,
-                                        vbm_setup_device_ptrs(e->H)->fft_wa[W], vbm_setup_device_ptrs(e->H)->window[W],
-                                        vbm_setup_device_ptrs(e->H)->window[0], v.N, s->blocksizes[0], v.ncb, q)); }
-        { TIMED(2, q); RUN(vbm_launch_transpose_in(&v, q)); }
-        // the transforms above read the block's PCM only; from here on the carried stream state is involved: the
-        // batches this batch's streams were last part of come first (those on this very HIP stream already do)
-        for (int ww = 0; ww < e->nws; ww++)
-            for (int t = 0; t < 4; t++)
-                if (((dep[m] >> (ww * 4 + t)) & 1u) && (e->slot_queue[ww][t] != qid || s->managed) &&
-                    (err = hipStreamWaitEvent(q, s->managed ? e->ev_done[ww][t] : e->ev_state[ww][t], 0)) != hipSuccess)
-                    return vbm_set_hip_error(err, "hipStreamWaitEvent");
-        { TIMED(3, q); RUN(vbm_launch_prologue(&v, q)); }
-        { TIMED(4, q); RUN(vbm_launch_noisemask(&v, q)); }
-        { TIMED(5, q); RUN(vbm_launch_tonemask(&v, s->psy[v.block_mode].total_octave_lines, q)); }
-        { TIMED(6, q);
-          if (s->managed) RUN(managed_front(v, q));
-          else { RUN(vbm_launch_mix(&v, q)); RUN(vbm_launch_block_state(&v, q)); } }
-        if ((err = hipEventRecord(e->ev_state[w][m], q)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
-        if (bigb) {   // hand over to the back-half stream of big batches
-            if ((err = hipStreamWaitEvent(e->sub[5], e->ev_state[w][m], 0)) != hipSuccess)
-                return vbm_set_hip_error(err, "big batch hand-over");
-            q = e->sub[5];
-        }
-        if (s->managed) {
-            TIMED(10, q);
-            RUN(managed_back(v, d_packets ? d_packets + (size_t)off[m] * e->max_packet_bytes : nullptr, q));
-        } else {
-            { TIMED(7, q); RUN(vbm_launch_floor_fit(&v, q)); }
-            { TIMED(8, q); RUN(vbm_launch_floor_encode(&v, q)); }
-            { TIMED(9, q); RUN(vbm_launch_couple_quantize(&v, q)); }
-            { TIMED(10, q); RUN(vbm_launch_pack(&v, q)); }
-        }
-        { TIMED(11, q);
-          if (d_packets && !s->managed)
-              RUN(vbm_launch_untranspose_i32((const int *)v.packetT, (int *)(d_packets + (size_t)off[m] * e->max_packet_bytes),
-                                             e->max_packet_bytes / 4, (size_t)(e->max_packet_bytes / 4) * 64, v.nsb, q));
-          if (d_packet_bytes &&
-              (err = hipMemcpyAsync(d_packet_bytes + off[m], v.packet_bytes, v.nsb * sizeof(int), hipMemcpyDeviceToDevice, q)) != hipSuccess)
-              return vbm_set_hip_error(err, "hipMemcpyAsync(packet_bytes)"); }
-#undef TIMED
-        if ((err = hipEventRecord(e->ev_done[w][m], q)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
-        return VBM_OK;
+        type_job j;
+        j.m = m; j.w = w; j.lane0 = pad[m]; j.bound = counts[m]; j.d_nsb = nullptr;
+        j.pcm = d_pcm + (size_t)off[m] * e->ch * s->blocksizes[1];
+        j.d_packets = d_packets ? d_packets + (size_t)off[m] * e->max_packet_bytes : nullptr;
+        j.d_packet_bytes = d_packet_bytes ? d_packet_bytes + off[m] : nullptr;
+        j.big = counts[m] >= kBigBatch;          // a big batch gets streams of its own (front / back half)
+        j.timed = prof && m == order[0];         // stage timing covers the round's largest batch (calling thread)
+        j.depmask = dep[m];
+        return enqueue_job(e, j);
     };
     int rcs[4] = {0, 0, 0, 0};
     std::string msgs[4];
@@ -986,6 +1022,119 @@ static int analysis_round_impl(vbm_encoder *e, const int *counts, const int *str
     }
     e->round_w = w;
     return defer ? VBM_OK : vbm_analysis_round_join(e, stream);
+}
+
+// ---- rounds built on the device (capi_frontend.cpp: vbm_frontend_encode_rounds_device) ------------------------------
+// The host knows neither which streams deliver a block nor how many: block type m owns the fixed lane region
+// [lane0[m], lane0[m] + cap[m]) of workspace w, its kernels are launched for cap[m] blocks and read the count from
+// d_count[m].  Order of a stream's blocks: the front end holds the streams of a call's first type-3 batch (the big
+// one) for the rest of the call, so a later round of the same call never holds a stream of it; every other batch
+// begun earlier may, and is waited for (its state event; a finished batch costs nothing).
+int vbm_encoder_device_round_open(vbm_encoder *e, hipStream_t fork, int *w_out, int **d_stream_id, uint8_t **d_wflags, int *lanes)
+{
+    int rc = vbm_encoder_set_sub_batches(e, e->nsplit);
+    if (rc) return rc;
+    while ((int)e->sub.size() < 6) {
+        hipStream_t q;
+        hipEvent_t ev;
+        if (hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return VBM_EHIP;
+        e->sub.push_back(q);
+        e->ev_join.push_back(ev);
+    }
+    const int w = e->next;
+    e->next = (e->next + 1) % e->nws;
+    e->cur = w;
+    hipError_t err;
+    if (e->back_pending[w]) {
+        if ((err = hipStreamWaitEvent(fork, e->ev_back[w], 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
+        e->back_pending[w] = false;
+    }
+    for (int m = 0; m < 4; m++)
+        if (e->reuse_pending[w][m]) {
+            if ((err = hipStreamWaitEvent(fork, e->ev_done[w][m], 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
+            e->reuse_pending[w][m] = false;
+        }
+    e->last_ids[w].clear();
+    e->last_flags[w].clear();
+    *w_out = w;
+    *d_stream_id = e->d_stream_id[w];
+    *d_wflags = e->d_wflags[w];
+    *lanes = e->Ls;
+    return VBM_OK;
+}
+
+int vbm_encoder_device_round_run(vbm_encoder *e, int w, const int *lane0, const int *cap, const int *d_count,
+                                 const float *d_blocks, uint8_t *d_packets, int *d_packet_bytes, bool first_round,
+                                 hipStream_t fork)
+{
+    const vbm_setup *s = e->hs;
+    hipError_t err;
+    for (int m = 0; m < 4; m++)
+        if (cap[m] < 0 || (lane0[m] & 63) || lane0[m] + cap[m] > e->Ls || (cap[m] && s->modes < 2 && (m >> 1))) return VBM_EINVAL;
+    if ((err = hipEventRecord(e->ev_fork, fork)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
+    e->last_nsb = 0;
+    if (first_round) e->call_big_w = -1;
+    // every slot that may still be running, except this round's own and the big batch of this call
+    unsigned depmask = 0;
+    for (int ww = 0; ww < e->nws; ww++)
+        for (int t = 0; t < 4; t++)
+            if (ww != w && e->reuse_pending[ww][t] && !(ww == e->call_big_w && t == 3)) depmask |= 1u << (ww * 4 + t);
+    const bool prof = e->profiling && e->prof_calls < e->prof_max_calls && e->events_used + 2 * (size_t)kNumStages <= e->events.size();
+    int dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    int rcs[4] = {0, 0, 0, 0};
+    std::string msgs[4];
+    std::thread workers[4];
+    const bool threaded = !getenv("VBM_ROUND_SINGLE_THREAD");
+    const int bigm = first_round ? 3 : -1;
+    auto job_of = [&](int m) {
+        type_job j;
+        j.m = m; j.w = w; j.lane0 = lane0[m]; j.bound = cap[m]; j.d_nsb = d_count + m;
+        j.pcm = d_blocks + (size_t)lane0[m] * e->ch * s->blocksizes[1];
+        j.d_packets = d_packets ? d_packets + (size_t)lane0[m] * e->max_packet_bytes : nullptr;
+        j.d_packet_bytes = d_packet_bytes ? d_packet_bytes + lane0[m] : nullptr;
+        j.big = m == bigm;
+        j.timed = prof && m == 3 && first_round;
+        j.depmask = depmask;
+        return j;
+    };
+    for (int m = 0; m < 4; m++) {
+        if (!cap[m] || m == 3) continue;
+        e->done_pending[w][m] = true;
+        e->reuse_pending[w][m] = true;
+        e->slot_queue[w][m] = (signed char)m;
+        e->epoch[w][m]++;
+        if (!threaded) {
+            rcs[m] = enqueue_job(e, job_of(m));
+            if (rcs[m]) msgs[m] = g_vbm_err;
+        } else {
+            workers[m] = std::thread([&, m]() {
+                (void)hipSetDevice(dev_id);
+                rcs[m] = enqueue_job(e, job_of(m));
+                if (rcs[m]) msgs[m] = g_vbm_err;
+            });
+        }
+    }
+    if (cap[3]) {      // the long blocks on the calling thread
+        e->done_pending[w][3] = true;
+        e->reuse_pending[w][3] = true;
+        e->slot_queue[w][3] = (signed char)(bigm == 3 ? 4 : 3);
+        e->epoch[w][3]++;
+        rcs[3] = enqueue_job(e, job_of(3));
+        if (rcs[3]) msgs[3] = g_vbm_err;
+    }
+    for (int m = 0; m < 4; m++)
+        if (workers[m].joinable()) workers[m].join();
+    for (int m = 0; m < 4; m++)
+        if (rcs[m]) { g_vbm_err = msgs[m]; return rcs[m]; }
+    if (prof && first_round) e->prof_calls++;
+    if (first_round) { e->call_big_w = w; e->lazy_w = w; e->lazy_m = 3; }
+    e->round_w = w;
+    // (per-stream bookkeeping of the host-built rounds does not apply: forget it, so that a later host-built round
+    // waits for everything instead of trusting stale entries)
+    e->device_rounds = true;
+    return VBM_OK;
 }
 
 extern "C" int vbm_analysis_round(vbm_encoder *e, const int *counts, const int *stream_ids, const uint8_t *wflags,

@@ -19,9 +19,14 @@
 #include "vbm_internal.h"
 
 vbm_setup_host *vbm_encoder_setup_host(vbm_encoder *e);
+vbm_setup_host *vbm_setup_handle_host(vbm_setup_handle *h);
 int vbm_encoder_streams(const vbm_encoder *e);
 int vbm_encoder_workspaces(const vbm_encoder *e);
 int vbm_encoder_reset_streams_dev(vbm_encoder *e, const int *d_ids, int n, hipStream_t q);
+int vbm_encoder_device_round_open(vbm_encoder *e, hipStream_t fork, int *w_out, int **d_stream_id, uint8_t **d_wflags, int *lanes);
+int vbm_encoder_device_round_run(vbm_encoder *e, int w, const int *lane0, const int *cap, const int *d_count,
+                                 const float *d_blocks, uint8_t *d_packets, int *d_packet_bytes, bool first_round,
+                                 hipStream_t fork);
 
 struct vbm_frontend {
     vbm_encoder *enc;
@@ -46,6 +51,15 @@ struct vbm_frontend {
     // is visible to the front end, and it waits for what the call promises (PCM consumed, packets complete).
     hipStream_t q = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    // rounds built on the device (vbm_frontend_encode_rounds_device)
+    int lane0[4] = {0, 0, 0, 0}, lane_cap[4] = {0, 0, 0, 0}, lanes = 0;
+    signed char *d_type = nullptr;        // [S]
+    int *d_slot = nullptr, *d_begin_lane = nullptr;       // [S], [lanes]
+    uint8_t *d_hold_call = nullptr;       // [S]
+    unsigned long long *d_stats = nullptr;   // [8]
+    float *d_blocks_dev = nullptr;        // [nblocks_bufs][lanes][ch][blocksizes[1]]
+    std::vector<long long> written;       // samples written per stream (start-of-stream detection without the mirrors)
+    bool mirrors_stale = false;           // device-built rounds ran: pcm_current / W / started are out of date
     bool dirty = false;                   // samples arrived since the envelope was last evaluated
     int pending_steps = 0;                // upper bound of search steps not yet evaluated
 };
@@ -169,6 +183,7 @@ extern "C" int vbm_frontend_create(vbm_frontend **out, vbm_encoder *enc)
     fe->W.assign(S, 0);
     fe->started.assign(S, 0);
     fe->ended.assign(S, 0);
+    fe->written.assign(S, 0);
     rc = vbm_frontend_reset(fe);
     if (rc) { vbm_frontend_destroy(fe); return rc; }
     *out = fe;
@@ -209,16 +224,21 @@ extern "C" int vbm_frontend_reset(vbm_frontend *fe)
     fe->W.assign(S, 0);
     fe->started.assign(S, 0);
     fe->ended.assign(S, 0);
+    fe->written.assign(S, 0);
+    fe->mirrors_stale = false;
     fe->dirty = false;
     fe->pending_steps = 0;
     return VBM_OK;
 }
+
+static int refresh_mirrors(vbm_frontend *fe);
 
 // most samples any stream holds (host mirror of pcm_current): lets the caller bound the rounds it runs
 // per write and still drain before the buffers fill
 extern "C" int vbm_frontend_max_buffered(const vbm_frontend *fe)
 {
     if (!fe) return VBM_EINVAL;
+    if (fe->mirrors_stale && refresh_mirrors(const_cast<vbm_frontend *>(fe))) return VBM_EHIP;
     int m = 0;
     for (int i = 0; i < fe->S; i++)
         if (fe->pcm_current[i] > m) m = fe->pcm_current[i];
@@ -237,7 +257,7 @@ extern "C" int vbm_frontend_write(vbm_frontend *fe, const float *d_pcm, int vals
     const int bs1 = s->blocksizes[1];
     for (int i = 0; i < fe->S; i++) {
         if (fe->ended[i]) { g_vbm_err = "vbm_frontend_write after vbm_frontend_finish"; return VBM_EINVAL; }
-        if (fe->pcm_current[i] + vals > fe->f.cap - 3 * bs1) {   // OV_EINVAL of lib/block.c:540-541
+        if (!fe->mirrors_stale && fe->pcm_current[i] + vals > fe->f.cap - 3 * bs1) {   // OV_EINVAL of lib/block.c:540-541
             g_vbm_err = "PCM buffer full: drain blocks with vbm_frontend_encode_round before writing more";
             return VBM_EINVAL;
         }
@@ -255,8 +275,10 @@ extern "C" int vbm_frontend_write(vbm_frontend *fe, const float *d_pcm, int vals
     bool cross = false;
     for (int i = 0; i < fe->S; i++) {
         fe->pcm_current[i] += vals;
-        // vorbis_analysis_wrote: first time more than one long block follows centerW (lib/block.c:547-550)
-        if (!fe->started[i] && fe->pcm_current[i] - bs1 / 2 > bs1) { fe->started[i] = 1; cross = true; }
+        fe->written[i] += vals;
+        // vorbis_analysis_wrote: first time more than one long block follows centerW (lib/block.c:547-550); before a
+        // stream starts nothing has left its buffer, so the samples written so far decide
+        if (!fe->started[i] && fe->written[i] > bs1) { fe->started[i] = 1; cross = true; }
     }
     if (cross && vbm_fe_launch_extrapolate(&fe->f, nullptr, 0, 0, bs1, st)) return VBM_EHIP;
     fe->dirty = true;
@@ -289,7 +311,7 @@ extern "C" int vbm_frontend_write_streams(vbm_frontend *fe, const int *stream_id
         if (i < 0 || i >= fe->S || seen[i]) return VBM_EINVAL;   // a stream once per call
         seen[i] = 1;
         if (fe->ended[i]) { g_vbm_err = "vbm_frontend_write_streams after vbm_frontend_finish"; return VBM_EINVAL; }
-        if (fe->pcm_current[i] + vals > fe->f.cap - 3 * bs1) {
+        if (!fe->mirrors_stale && fe->pcm_current[i] + vals > fe->f.cap - 3 * bs1) {
             g_vbm_err = "PCM buffer full: drain blocks with vbm_frontend_encode_round before writing more";
             return VBM_EINVAL;
         }
@@ -304,7 +326,8 @@ extern "C" int vbm_frontend_write_streams(vbm_frontend *fe, const int *stream_id
     for (int k = 0; k < n; k++) {
         const int i = stream_ids[k];
         fe->pcm_current[i] += vals;
-        if (!fe->started[i] && fe->pcm_current[i] - bs1 / 2 > bs1) { fe->started[i] = 1; cross = true; }
+        fe->written[i] += vals;
+        if (!fe->started[i] && fe->written[i] > bs1) { fe->started[i] = 1; cross = true; }
     }
     if (cross && vbm_fe_launch_extrapolate(&fe->f, nullptr, 0, 0, bs1, st)) return VBM_EHIP;
     (void)hipStreamSynchronize(st);   // d_ids / h_ids are free again
@@ -335,6 +358,7 @@ extern "C" int vbm_frontend_restart_streams(vbm_frontend *fe, const int *stream_
         fe->W[i] = 0;
         fe->started[i] = 0;
         fe->ended[i] = 0;
+        fe->written[i] = 0;
     }
     return VBM_OK;
 }
@@ -372,11 +396,34 @@ extern "C" int vbm_frontend_finish(vbm_frontend *fe, const int *stream_ids, int 
 
 static vbm_encoder *vbm_frontend_encoder(vbm_frontend *fe) { return fe->enc; }
 
+// Rounds built on the device leave the host mirrors behind: fetch what the host-built rounds need (buffer fill,
+// current window size, whether a stream can deliver blocks) once the front end's stream has drained.
+static int refresh_mirrors(vbm_frontend *fe)
+{
+    if (!fe->mirrors_stale) return VBM_OK;
+    const int S = fe->S;
+    std::vector<int> pre(S), eof(S);
+    hipError_t err;
+    if ((err = hipStreamSynchronize(fe->q)) != hipSuccess ||
+        (err = hipMemcpy(fe->pcm_current.data(), fe->f.pcm_current, S * sizeof(int), hipMemcpyDeviceToHost)) != hipSuccess ||
+        (err = hipMemcpy(fe->W.data(), fe->f.W, S * sizeof(int), hipMemcpyDeviceToHost)) != hipSuccess ||
+        (err = hipMemcpy(pre.data(), fe->f.preextrapolate, S * sizeof(int), hipMemcpyDeviceToHost)) != hipSuccess ||
+        (err = hipMemcpy(eof.data(), fe->f.eofflag, S * sizeof(int), hipMemcpyDeviceToHost)) != hipSuccess)
+        return vbm_set_hip_error(err, "front end mirrors");
+    for (int i = 0; i < S; i++) fe->started[i] = (pre[i] && eof[i] != -1) ? 1 : 0;
+    fe->mirrors_stale = false;
+    return VBM_OK;
+}
+
 static int round_impl(vbm_frontend *fe, uint8_t *d_packets, int *d_packet_bytes, vbm_packet_info *info, int *nblocks,
                       void *stream, bool defer)
 {
     if (!fe || !nblocks || !info) return VBM_EINVAL;
     *nblocks = 0;
+    {
+        int rcm = refresh_mirrors(fe);
+        if (rcm) return rcm;
+    }
     const vbm_setup *s = fe->hs;
     const vbm_setup *ds = vbm_setup_device(fe->H);
     const int S = fe->S, ch = fe->ch;
@@ -462,7 +509,7 @@ static int round_impl(vbm_frontend *fe, uint8_t *d_packets, int *d_packet_bytes,
         if (!count[m]) continue;
         const int N = (m >> 1) ? bs1 : bs0;
         float *blocks = round_blocks + (size_t)offset[m] * ch * bs1;
-        if (vbm_fe_launch_gather(&fe->f, fe->d_ids + offset[m], fe->d_begin + offset[m], count[m], N, blocks, st))
+        if (vbm_fe_launch_gather(&fe->f, fe->d_ids + offset[m], fe->d_begin + offset[m], count[m], N, blocks, nullptr, st))
             return VBM_EHIP;
     }
     {
@@ -590,6 +637,136 @@ extern "C" int vbm_packets_compact(const uint8_t *d_packets, const int *d_packet
     if (((uintptr_t)d_packets & 3) || ((uintptr_t)d_out & 3)) return VBM_EINVAL;
     return vbm_launch_compact(d_packets, d_packet_bytes, n, max_packet_bytes, d_offsets, d_out, (hipStream_t)stream)
                ? VBM_EHIP : VBM_OK;
+}
+
+// ---- rounds built on the device -----------------------------------------------------------------------------
+// Lane regions of a round, in the order of the block types: the three small types (impulse, padding, transition)
+// get a quarter of the stream count each (at least 256 lanes), the long blocks (type 3) one lane per stream, last.
+// (The order matters: the block-major arrays of a workspace are addressed lane * n with the type's own n, so the
+// regions of the short types have to lie BELOW those of the long ones, as in the host-built rounds.)
+// Setups with one block size only deliver types 0 and 1: a full region each.
+static void lane_layout(const vbm_setup *s, int S, int *lane0, int *cap, int *lanes)
+{
+    const int S64 = (S + 63) & ~63;
+    if (s->modes < 2) {
+        lane0[0] = 0; cap[0] = S; lane0[1] = S64; cap[1] = S;
+        lane0[2] = lane0[3] = 2 * S64; cap[2] = cap[3] = 0;
+        *lanes = 2 * S64;
+        return;
+    }
+    int q = ((S / 4) + 63) & ~63;
+    if (q < 256) q = 256;
+    if (q > S64) q = S64;
+    const int c = q < S ? q : S;
+    lane0[0] = 0; cap[0] = c;
+    lane0[1] = q; cap[1] = c;
+    lane0[2] = 2 * q; cap[2] = c;
+    lane0[3] = 3 * q; cap[3] = S;
+    *lanes = 3 * q + S64;
+}
+
+extern "C" int vbm_device_round_lanes(const vbm_setup_handle *setup, int nstreams)
+{
+    if (!setup || nstreams <= 0) return VBM_EINVAL;
+    int lane0[4], cap[4], lanes;
+    lane_layout(vbm_setup_host_view(vbm_setup_handle_host(const_cast<vbm_setup_handle *>(setup))), nstreams, lane0, cap, &lanes);
+    return lanes;
+}
+
+extern "C" int vbm_frontend_encode_rounds_device(vbm_frontend *fe, int nrounds, uint8_t *d_packets, int *d_packet_bytes,
+                                                 vbm_packet_info *d_info, int *d_counts, int lazy, void *stream)
+{
+    if (!fe || nrounds < 1 || !d_packet_bytes || !d_info || !d_counts) return VBM_EINVAL;
+    const vbm_setup *s = fe->hs;
+    const vbm_setup *ds = vbm_setup_device(fe->H);
+    const int S = fe->S, ch = fe->ch, bs0 = s->blocksizes[0], bs1 = s->blocksizes[1];
+    const int maxb = vbm_encoder_max_packet_bytes(fe->enc);
+    hipStream_t q = fe->q;
+    hipError_t err;
+    int rc = fe_enter(fe, stream);
+    if (rc) return rc;
+    if (!fe->lanes) {
+        lane_layout(s, S, fe->lane0, fe->lane_cap, &fe->lanes);
+        const size_t L = (size_t)fe->lanes;
+#define A(field, type, count) do { type *p_; rc = fe_alloc<type>(fe, &p_, (count)); if (rc) return rc; field = p_; } while (0)
+        A(fe->d_type, signed char, (size_t)S);
+        A(fe->d_slot, int, (size_t)S);
+        A(fe->d_begin_lane, int, L);
+        A(fe->d_hold_call, uint8_t, (size_t)S);
+        A(fe->d_stats, unsigned long long, 8);
+        A(fe->d_blocks_dev, float, (size_t)fe->nblocks_bufs * L * ch * bs1);
+#undef A
+    }
+    // evaluate the envelope over everything written since the last round (_ve_envelope_search, first part)
+    if (fe->dirty) {
+        if (vbm_fe_launch_ve_range(&fe->f, q)) return VBM_EHIP;
+        vbm_ve_gather g;
+        g.pcm = fe->f.pcm;
+        g.first = fe->f.ve_first; g.last = fe->f.ve_last; g.parity = fe->f.parity;
+        g.ch = ch; g.steps = VBM_FE_CHUNK; g.cap = fe->f.cap; g.plane = fe->f.plane;
+        for (int t0 = 0; t0 < fe->pending_steps; t0 += VBM_FE_CHUNK) {
+            g.t0 = t0;
+            if (vbm_launch_ve_mdct(&g, fe->f.ve_spec, vbm_setup_device_ptrs(fe->H)->ve.mdct_trig,
+                                   vbm_setup_device_ptrs(fe->H)->ve.mdct_win, (long)S * ch * VBM_FE_CHUNK, q))
+                return VBM_EHIP;
+            if (vbm_fe_launch_ve_filter(&fe->f, ds, t0, q)) return VBM_EHIP;
+        }
+        fe->dirty = false;
+        fe->pending_steps = 0;
+    }
+    if ((err = hipMemsetAsync(fe->d_hold_call, 0, (size_t)S, q)) != hipSuccess) return vbm_set_hip_error(err, "hipMemsetAsync(hold)");
+    for (int r = 0; r < nrounds; r++) {
+        int w, ws_lanes;
+        int *d_sid;
+        uint8_t *d_wf;
+        rc = vbm_encoder_device_round_open(fe->enc, q, &w, &d_sid, &d_wf, &ws_lanes);
+        if (rc) return rc;
+        if (ws_lanes < fe->lanes) {
+            g_vbm_err = "encoder workspace too small for rounds built on the device: create it with max_batch >= vbm_device_round_lanes()";
+            return VBM_EINVAL;
+        }
+        float *blocks = fe->d_blocks_dev + (size_t)w * fe->lanes * ch * bs1;
+        int *counts_r = d_counts + 4 * r;
+        int *bytes_r = d_packet_bytes + (size_t)r * fe->lanes;
+        vbm_fe_round R;
+        for (int m = 0; m < 4; m++) { R.lane0[m] = fe->lane0[m]; R.cap[m] = fe->lane_cap[m]; }
+        R.first_round = r == 0;
+        R.count = counts_r;
+        R.slot = fe->d_slot;
+        R.hold = fe->d_hold_call;
+        R.stream_id = d_sid;
+        R.wflags = d_wf;
+        R.begin = fe->d_begin_lane;
+        R.info = d_info + (size_t)r * fe->lanes;
+        R.stats = fe->d_stats;
+        if (vbm_fe_launch_round_plan(&fe->f, ds, &R, fe->d_type, fe->d_dec, bytes_r, fe->lanes, q)) return VBM_EHIP;
+        for (int m = 0; m < 4; m++) {
+            if (!fe->lane_cap[m]) continue;
+            const int N = (m >> 1) ? bs1 : bs0;
+            if (vbm_fe_launch_gather(&fe->f, d_sid + fe->lane0[m], fe->d_begin_lane + fe->lane0[m], fe->lane_cap[m], N,
+                                     blocks + (size_t)fe->lane0[m] * ch * bs1, counts_r + m, q))
+                return VBM_EHIP;
+        }
+        rc = vbm_encoder_device_round_run(fe->enc, w, fe->lane0, fe->lane_cap, counts_r, blocks,
+                                          d_packets ? d_packets + (size_t)r * fe->lanes * maxb : nullptr, bytes_r, r == 0, q);
+        if (rc) return rc;
+        if (vbm_fe_launch_shift(&fe->f, fe->d_dec, q)) return VBM_EHIP;
+    }
+    fe->mirrors_stale = true;
+    return lazy ? vbm_analysis_round_join_lazy(fe->enc, stream) : vbm_analysis_round_join(fe->enc, stream);
+}
+
+// running totals of the rounds built on the device: blocks of type 0..3 and the samples all streams advanced by
+extern "C" int vbm_frontend_device_stats(vbm_frontend *fe, unsigned long long *out)
+{
+    if (!fe || !out) return VBM_EINVAL;
+    for (int i = 0; i < 5; i++) out[i] = 0;
+    if (!fe->d_stats) return VBM_OK;
+    hipError_t err;
+    if ((err = hipStreamSynchronize(fe->q)) != hipSuccess ||
+        (err = hipMemcpy(out, fe->d_stats, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost)) != hipSuccess)
+        return vbm_set_hip_error(err, "hipMemcpy(stats)");
+    return VBM_OK;
 }
 
 extern "C" int vbm_frontend_join(vbm_frontend *fe, void *stream)

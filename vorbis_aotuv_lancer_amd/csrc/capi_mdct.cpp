@@ -188,7 +188,7 @@ extern "C" int vbm_mdct_forward_batch(const vbm_mdct_plan *p, const float *d_in,
     int rc = check_batch_args(p, d_in, d_out, nblocks);
     if (rc) return rc;
     rc = vbm_launch_window_mdct(d_in, d_out, nullptr, p->d_trig, nullptr, nullptr, p->n, p->short_n,
-                                0, nblocks, 0, (hipStream_t)stream);
+                                0, nblocks, 0, nullptr, 0, (hipStream_t)stream);
     return rc ? VBM_EHIP : VBM_OK;
 }
 
@@ -199,7 +199,7 @@ extern "C" int vbm_window_mdct_batch(const vbm_mdct_plan *p, const float *d_pcm,
     if (rc) return rc;
     if (!p->has_window) return VBM_EINVAL;
     rc = vbm_launch_window_mdct(d_pcm, d_out, p->d_win_short ? d_wflags : nullptr, p->d_trig, p->d_win_n, p->d_win_short,
-                                p->n, p->short_n, 1, nblocks, 0, (hipStream_t)stream);
+                                p->n, p->short_n, 1, nblocks, 0, nullptr, 0, (hipStream_t)stream);
     return rc ? VBM_EHIP : VBM_OK;
 }
 
@@ -211,7 +211,7 @@ extern "C" int vbm_window_fft_log_batch(const vbm_mdct_plan *p, const float *d_p
     if (rc) return rc;
     if (!p->has_window || (nblocks > 0 && !d_local_ampmax)) return VBM_EINVAL;
     rc = vbm_launch_window_fft_log(d_pcm, d_logfft, d_local_ampmax, p->d_win_short ? d_wflags : nullptr, p->d_fftwa,
-                                   p->d_win_n, p->d_win_short, p->n, p->short_n, nblocks, (hipStream_t)stream);
+                                   p->d_win_n, p->d_win_short, p->n, p->short_n, nblocks, nullptr, 0, (hipStream_t)stream);
     return rc ? VBM_EHIP : VBM_OK;
 }
 

@@ -234,8 +234,12 @@ void k_window_fft_log(const float *__restrict__ pcm, float *__restrict__ logfft,
                       float *__restrict__ local_ampmax, const uint8_t *__restrict__ wflags,
                       const float *__restrict__ wa_g,      // FFTPACK twiddles, N floats (trigcache + N)
                       const float *__restrict__ win_self, const float *__restrict__ win_short,
-                      int short_n, long nblocks)
+                      int short_n, long nblocks, const int *__restrict__ d_live, int live_mult)
 {
+    if (d_live) {
+        const long live = (long)*d_live * live_mult;
+        if (live < nblocks) nblocks = live;
+    }
     __shared__ __attribute__((aligned(16))) float s_wa[N];
     __shared__ __attribute__((aligned(16))) float s_win[N / 2];
     __shared__ __attribute__((aligned(16))) float s_wshort[N / 4];   // rising half-window of a short block (<= N/2 long)
@@ -326,7 +330,7 @@ void k_window_fft_log(const float *__restrict__ pcm, float *__restrict__ logfft,
 extern "C" int vbm_launch_window_fft_log(const float *d_pcm, float *d_logfft, float *d_local_ampmax,
                                          const uint8_t *d_wflags, const float *d_wa, const float *d_win_self,
                                          const float *d_win_short, int n, int short_n, long nblocks,
-                                         hipStream_t stream)
+                                         const int *d_live, int live_mult, hipStream_t stream)
 {
     if (nblocks <= 0) return 0;
     if (n != 4096 && n != 2048 && n != 1024 && n != 512 && n != 256) return -1;
@@ -336,7 +340,7 @@ extern "C" int vbm_launch_window_fft_log(const float *d_pcm, float *d_logfft, fl
     dim3 grid((unsigned)wgs), block(64 * nw);
 #define LAUNCH_FFT(NN)                                                                                              \
     hipLaunchKernelGGL(k_window_fft_log<NN>, grid, block, 0, stream, d_pcm, d_logfft, d_local_ampmax, d_wflags, d_wa, \
-                       d_win_self, d_win_short, short_n, nblocks)
+                       d_win_self, d_win_short, short_n, nblocks, d_live, live_mult)
     if (n == 4096) LAUNCH_FFT(4096);
     else if (n == 2048) LAUNCH_FFT(2048);
     else if (n == 1024) LAUNCH_FFT(1024);

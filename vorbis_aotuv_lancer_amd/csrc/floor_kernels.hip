@@ -170,12 +170,12 @@ __global__ void k_floor_prep(vbm_batch b)
     {
         const int c = c0 + tx;
         float att = 0.f;
-        if (c < b.ncb) att = s->floor[map->floorsubmap[map->chmuxlist[c % b.ch]]].twofitatten;
+        if (c < vbm_ncb(b)) att = s->floor[map->floorsubmap[map->chmuxlist[c % b.ch]]].twofitatten;
         const size_t tb = (size_t)(c >> 6) * b.slab_words + (c & 63);
         for (int rr = ty; rr < 64; rr += 4) {
             const int r = r0 + rr;
             uint16_t w = 0;
-            if (c < b.ncb && r < b.n) {
+            if (c < vbm_ncb(b) && r < b.n) {
                 const float fl = T(b.logmaskT, r);
                 w = (uint16_t)(dBquant(fl) | ((T(b.logmdctT, r) + att >= fl) ? 0x8000 : 0));
             }
@@ -185,7 +185,7 @@ __global__ void k_floor_prep(vbm_batch b)
     __syncthreads();
     for (int cc = ty; cc < 64; cc += 4) {
         const int c = c0 + cc, r = r0 + tx;
-        if (c < b.ncb && r < b.n) b.qf_bm[(size_t)c * b.n + r] = tile[tx][cc];
+        if (c < vbm_ncb(b) && r < b.n) b.qf_bm[(size_t)c * b.n + r] = tile[tx][cc];
     }
 }
 
@@ -194,7 +194,7 @@ __global__ void k_floor_fit(vbm_batch b, int lpw)
 {
     extern __shared__ int fit_lds[];   // LDS: [(posts - 1) * 10][64]
     const int lane = blockIdx.x * lpw + threadIdx.x;
-    if ((int)threadIdx.x >= lpw || lane >= b.ncb) return;
+    if ((int)threadIdx.x >= lpw || lane >= vbm_ncb(b)) return;
     const size_t tb = (size_t)(lane >> 6) * b.slab_words + (lane & 63);
     qf_window qf;
     qf.row = b.qf_bm + (size_t)lane * b.n;   // rows are 16-byte aligned: n is a multiple of 8
@@ -430,7 +430,7 @@ __global__ void k_floor_fit(vbm_batch b, int lpw)
 __global__ void k_floor_interp(vbm_batch b)
 {
     const int lane = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lane >= b.ncb) return;
+    if (lane >= vbm_ncb(b)) return;
     const size_t tb = (size_t)(lane >> 6) * b.slab_words + (lane & 63);
     const vbm_setup *s = b.setup;
     const int c = lane % b.ch;
@@ -464,7 +464,7 @@ __global__ void k_floor_interp(vbm_batch b)
 __global__ void k_floor_encode(vbm_batch b)
 {
     const int lane = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lane >= b.ncb) return;
+    if (lane >= vbm_ncb(b)) return;
     const size_t tb = (size_t)(lane >> 6) * b.slab_words + (lane & 63);
     const vbm_setup *s = b.setup;
     const int c = lane % b.ch;
@@ -537,7 +537,7 @@ __global__ void k_floor_encode(vbm_batch b)
 __global__ void k_floor_render(vbm_batch b, int nchunks)
 {
     const int lane = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lane >= b.ncb) return;
+    if (lane >= vbm_ncb(b)) return;
     const size_t tb = (size_t)(lane >> 6) * b.slab_words + (lane & 63);
     const vbm_setup *s = b.setup;
     const int c = lane % b.ch;

@@ -10,6 +10,7 @@
 #pragma once
 #include <stdint.h>
 #include "setup.h"
+#include "vorbis_mi355x.h"   /* vbm_packet_info */
 
 #define VBM_FE_CHUNK 32          /* search steps evaluated per launch of the envelope kernels */
 
@@ -45,3 +46,19 @@ struct vbm_fe_decision {
     int movement;                // samples the buffer moves down after this block
     long long granulepos, sequence;
 };
+
+// One round built on the device (k_fe_classify / k_fe_plan / k_fe_commit): block type m owns the lane region
+// [lane0[m], lane0[m] + cap[m]) of the round's lists and of the encoder workspace behind them.
+struct vbm_fe_round {
+    int lane0[4], cap[4];
+    int first_round;             // first round of a call: its type-3 streams are held for the call's later rounds
+    int *count;                  // [4] device: blocks of each type this round (<= cap)
+    int *slot;                   // [S] lane of the stream's block this round, -1 none
+    uint8_t *hold;               // [S] streams left alone for the rest of the call
+    int *stream_id;              // [lanes]  (the encoder workspace's own list)
+    uint8_t *wflags;             // [lanes]
+    int *begin;                  // [lanes] first sample of the block in its stream's buffer
+    vbm_packet_info *info;       // [lanes] description of every lane's block (stream = -1: none)
+    unsigned long long *stats;   // [5] running totals: blocks of type 0..3, samples the streams advanced by
+};
+

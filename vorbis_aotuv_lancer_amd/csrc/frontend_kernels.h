@@ -14,6 +14,8 @@ int vbm_fe_launch_ve_filter(const vbm_fe_state *f, const vbm_setup *d_setup, int
 int vbm_fe_launch_decide(const vbm_fe_state *f, const vbm_setup *d_setup, vbm_fe_decision *d_out, const uint8_t *d_hold,
                          hipStream_t st);
 int vbm_fe_launch_gather(const vbm_fe_state *f, const int *d_ids, const int *d_begin, int count, int N, float *d_dst,
-                         hipStream_t st);
+                         const int *d_count, hipStream_t st);
+int vbm_fe_launch_round_plan(const vbm_fe_state *f, const vbm_setup *d_setup, const vbm_fe_round *r, signed char *d_type,
+                             vbm_fe_decision *d_dec, int *d_packet_bytes, int lanes, hipStream_t st);
 int vbm_fe_launch_shift(const vbm_fe_state *f, const vbm_fe_decision *d_dec, hipStream_t st);
 }

@@ -400,16 +400,17 @@ __global__ __launch_bounds__(64) void k_fe_ve_filter(vbm_fe_state f, const vbm_s
 }
 
 // ---------------------------------------------------------------------------------------------
-// hold (may be NULL): streams marked there are left alone in this round (no block, no state change)
-__global__ void k_fe_decide(vbm_fe_state f, const vbm_setup *__restrict__ setup, vbm_fe_decision *__restrict__ out,
-                            const uint8_t *__restrict__ hold)
+// vorbis_analysis_blockout for stream s (lib/block.c:557-812, _ve_envelope_search's cursor walk lib/envelope.c:627-680,
+// _ve_envelope_mark :683-707, _ve_envelope_shift :709-728) without its copies.  COMMIT = false evaluates the same
+// decision without touching the stream (what WOULD come out): the device-built rounds first look, then assign
+// lanes, then commit (k_fe_classify / k_fe_plan / k_fe_commit).
+template <bool COMMIT>
+__device__ __forceinline__ void fe_decide_one(const vbm_fe_state &f, const vbm_setup *__restrict__ setup, const int s,
+                                              vbm_fe_decision &d)
 {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= f.S) return;
     const int S = f.S;
     const int searchstep = 64;
     const int bs0 = setup->blocksizes[0], bs1 = setup->blocksizes[1];
-    vbm_fe_decision d;
     d.ready = 0; d.lW = d.W = d.nW = 0; d.block_mode = 0; d.eos = 0; d.beginW = 0; d.movement = 0;
     d.granulepos = 0; d.sequence = 0;
 
@@ -418,21 +419,20 @@ __global__ void k_fe_decide(vbm_fe_state f, const vbm_setup *__restrict__ setup,
     const int bsW = W ? bs1 : bs0;
     const int beginW = centerW - bsW / 2;
 
-    if (!f.preextrapolate[s] || eofflag == -1 || (hold && hold[s])) {
-        out[s] = d;
-        return;
-    }
+    if (!f.preextrapolate[s] || eofflag == -1) return;
 
     // _ve_envelope_search, after its evaluation loop (lib/envelope.c:627-680)
     int bp = -1;
+    int curmark;
     {
         // ve->current = last * searchstep with last recomputed from the present pcm_current; every step
         // below it has been evaluated by k_fe_ve_filter before this kernel runs
         const int ve_current = (pcm_current / searchstep - VBM_VE_WIN) * searchstep;
-        f.ve_current[s] = ve_current;
+        if (COMMIT) f.ve_current[s] = ve_current;
         const int testW = centerW + bsW / 4 + bs1 / 2 + bs0 / 4;
         int j = f.ve_cursor[s];
-        int cursor = j, curmark = f.ve_curmark[s];
+        int cursor = j;
+        curmark = f.ve_curmark[s];
         while (j < ve_current - searchstep) {
             if (j >= testW) { bp = 1; break; }
             cursor = j;
@@ -445,29 +445,25 @@ __global__ void k_fe_decide(vbm_fe_state f, const vbm_setup *__restrict__ setup,
             }
             j += searchstep;
         }
-        f.ve_cursor[s] = cursor;
-        f.ve_curmark[s] = curmark;
+        if (COMMIT) {
+            f.ve_cursor[s] = cursor;
+            f.ve_curmark[s] = curmark;
+        }
     }
 
     if (bp == -1) {
-        if (eofflag == 0) {   // not enough data yet
-            out[s] = d;
-            return;
-        }
+        if (eofflag == 0) return;   // not enough data yet
         nW = 0;
     } else {
         nW = (bs0 == bs1) ? 0 : bp;
     }
-    f.nW[s] = nW;
+    if (COMMIT) f.nW[s] = nW;
 
     const int bsn = nW ? bs1 : bs0;
     const int centerNext = centerW + bsW / 4 + bsn / 4;
     {
         const int blockbound = centerNext + bsn / 2;
-        if (pcm_current < blockbound) {
-            out[s] = d;
-            return;
-        }
+        if (pcm_current < blockbound) return;
     }
 
     // the block (lib/block.c:606-651)
@@ -480,7 +476,6 @@ __global__ void k_fe_decide(vbm_fe_state f, const vbm_setup *__restrict__ setup,
         // _ve_envelope_mark (lib/envelope.c:683-707)
         int b0 = centerW - bs0 / 4 - bs0 / 4;
         int e0 = centerW + bs0 / 4 + bs0 / 4;
-        const int curmark = f.ve_curmark[s];
         int marked = 0;
         if (curmark >= b0 && curmark < e0) marked = 1;
         else {
@@ -491,6 +486,7 @@ __global__ void k_fe_decide(vbm_fe_state f, const vbm_setup *__restrict__ setup,
         blocktype = marked ? 0 /* BLOCKTYPE_IMPULSE */ : 1 /* BLOCKTYPE_PADDING */;
     }
     d.block_mode = blocktype | (W << 1);
+    if (!COMMIT) return;
     d.sequence = f.sequence[s]++;
     long long granulepos = f.granulepos[s];
     d.granulepos = granulepos;
@@ -500,7 +496,6 @@ __global__ void k_fe_decide(vbm_fe_state f, const vbm_setup *__restrict__ setup,
         if (centerW >= eofflag) {
             f.eofflag[s] = -1;
             d.eos = 1;
-            out[s] = d;
             return;
         }
     }
@@ -543,16 +538,143 @@ __global__ void k_fe_decide(vbm_fe_state f, const vbm_setup *__restrict__ setup,
             f.granulepos[s] = granulepos;
         }
     }
+}
+
+// hold (may be NULL): streams marked there are left alone in this round (no block, no state change)
+__global__ void k_fe_decide(vbm_fe_state f, const vbm_setup *__restrict__ setup, vbm_fe_decision *__restrict__ out,
+                            const uint8_t *__restrict__ hold)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= f.S) return;
+    vbm_fe_decision d;
+    if (hold && hold[s]) {
+        d.ready = 0; d.lW = d.W = d.nW = 0; d.block_mode = 0; d.eos = 0; d.beginW = 0; d.movement = 0;
+        d.granulepos = 0; d.sequence = 0;
+    } else {
+        fe_decide_one<true>(f, setup, s, d);
+    }
     out[s] = d;
+}
+
+// ---- rounds built on the device ----------------------------------------------------------------------------
+// k_fe_classify: which block type would every stream deliver now (-1: none)?  Nothing is changed.
+__global__ void k_fe_classify(vbm_fe_state f, const vbm_setup *__restrict__ setup, const uint8_t *__restrict__ hold,
+                              signed char *__restrict__ type)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= f.S) return;
+    vbm_fe_decision d;
+    d.ready = 0;
+    if (!hold[s]) fe_decide_one<false>(f, setup, s, d);
+    type[s] = d.ready ? (signed char)(d.block_mode & 3) : (signed char)-1;
+}
+
+// k_fe_plan (one workgroup): lanes for the blocks of a round.  Block type m owns the fixed lane region
+// [lane0[m], lane0[m] + cap[m]); inside it the streams follow in ascending order.  A stream whose type's region is
+// full keeps its block for the next round (rounds may be deferred: blocks and packets do not depend on when they
+// run).  Streams that deliver a block of the big type (3) in the first round of a call are left alone for the
+// rest of the call (hold), so that no later batch of the call has to wait for the big one.
+__global__ __launch_bounds__(1024) void k_fe_plan(vbm_fe_round r, const signed char *__restrict__ type, int S)
+{
+    __shared__ int s_part[16][4];
+    __shared__ int s_carry[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < 4) s_carry[threadIdx.x] = 0;
+    __syncthreads();
+    for (int base = 0; base < S; base += 1024) {
+        const int s = base + threadIdx.x;
+        const int t = s < S ? type[s] : -1;
+        int incl[4], mine[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            mine[m] = (t == m) ? 1 : 0;
+            int v = mine[m];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int u = __shfl_up(v, d);
+                if (lane >= d) v += u;
+            }
+            incl[m] = v;
+            if (lane == 63) s_part[wave][m] = v;
+        }
+        __syncthreads();
+        if (s < S) {
+            int slot = -1;
+            if (t >= 0) {
+                int before = s_carry[t];
+                for (int w = 0; w < wave; w++) before += s_part[w][t];
+                const int rank = before + incl[t] - 1;
+                if (rank < r.cap[t]) slot = r.lane0[t] + rank;
+            }
+            r.slot[s] = slot;
+            if (slot >= 0 && t == 3 && r.first_round) r.hold[s] = 1;
+        }
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            int tot = s_carry[threadIdx.x];
+            for (int w = 0; w < 16; w++) tot += s_part[w][threadIdx.x];
+            s_carry[threadIdx.x] = tot;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) {
+        const int m = threadIdx.x;
+        const int n = s_carry[m] < r.cap[m] ? s_carry[m] : r.cap[m];
+        r.count[m] = n;
+        atomicAdd(&r.stats[m], (unsigned long long)n);
+    }
+}
+
+// k_fe_commit: the streams that got a lane deliver their block (state changes as in k_fe_decide) and describe it in
+// the lane's entries of the round's lists; every other stream is left alone.
+__global__ void k_fe_commit(vbm_fe_state f, const vbm_setup *__restrict__ setup, vbm_fe_round r,
+                            vbm_fe_decision *__restrict__ dec)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= f.S) return;
+    vbm_fe_decision d;
+    d.ready = 0; d.lW = d.W = d.nW = 0; d.block_mode = 0; d.eos = 0; d.beginW = 0; d.movement = 0;
+    d.granulepos = 0; d.sequence = 0;
+    const int slot = r.slot[s];
+    if (slot >= 0) {
+        fe_decide_one<true>(f, setup, s, d);
+        // (the look of k_fe_classify and this decision see the same state: d.ready holds)
+        r.stream_id[slot] = s;
+        r.wflags[slot] = (uint8_t)(d.lW | (d.nW << 1));
+        r.begin[slot] = d.beginW;
+        vbm_packet_info pi;
+        pi.stream = s; pi.block_mode = d.block_mode; pi.lW = d.lW; pi.W = d.W; pi.nW = d.nW; pi.eos = d.eos;
+        pi.granulepos = d.granulepos; pi.packetno = d.sequence;
+        r.info[slot] = pi;
+        if (d.movement > 0) atomicAdd(&r.stats[4], (unsigned long long)d.movement);
+    }
+    dec[s] = d;
+}
+
+// lanes of a region beyond its count: no block (stream -1, length -2)
+__global__ void k_fe_blank(vbm_fe_round r, int *__restrict__ packet_bytes, int lanes)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= lanes) return;
+    int m = 3;
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+        if (k >= r.lane0[t] && k < r.lane0[t] + r.cap[t]) m = t;
+    const bool inside = k >= r.lane0[m] && k < r.lane0[m] + r.cap[m];
+    if (!inside || k - r.lane0[m] >= r.count[m]) {
+        r.info[k].stream = -1;
+        packet_bytes[k] = -2;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
 // blocks of one block type: dst[k][c][N] <- channel buffers of stream ids[k] at begin[k]
 __global__ void k_fe_gather(vbm_fe_state f, const int *__restrict__ ids, const int *__restrict__ begin, int count,
-                            int N, float *__restrict__ dst)
+                            int N, float *__restrict__ dst, const int *__restrict__ d_count)
 {
     const int kc = blockIdx.x;                      // block k, channel c
     const int k = kc / f.ch, c = kc % f.ch;
+    if (d_count) count = *d_count;                  // round built on the device: `count` was the launch bound
     if (k >= count) return;
     const int s = ids[k];
     // the shift of this round has not run yet: parity and contents are those the decision saw
@@ -641,11 +763,24 @@ extern "C" int vbm_fe_launch_decide(const vbm_fe_state *f, const vbm_setup *d_se
 }
 
 extern "C" int vbm_fe_launch_gather(const vbm_fe_state *f, const int *d_ids, const int *d_begin, int count, int N,
-                                    float *d_dst, hipStream_t st)
+                                    float *d_dst, const int *d_count, hipStream_t st)
 {
     if (count <= 0) return 0;
     hipLaunchKernelGGL(k_fe_gather, dim3((unsigned)(count * f->ch), (unsigned)((N / 4 + 255) / 256)), dim3(256), 0, st, *f,
-                       d_ids, d_begin, count, N, d_dst);
+                       d_ids, d_begin, count, N, d_dst, d_count);
+    return CHECK_LAUNCH();
+}
+
+// a round built on the device: look, assign lanes, commit, blank the unused lanes (frontend.h: vbm_fe_round)
+extern "C" int vbm_fe_launch_round_plan(const vbm_fe_state *f, const vbm_setup *d_setup, const vbm_fe_round *r,
+                                        signed char *d_type, vbm_fe_decision *d_dec, int *d_packet_bytes, int lanes,
+                                        hipStream_t st)
+{
+    const dim3 g((unsigned)((f->S + 63) / 64));
+    hipLaunchKernelGGL(k_fe_classify, g, dim3(64), 0, st, *f, d_setup, r->hold, d_type);
+    hipLaunchKernelGGL(k_fe_plan, dim3(1), dim3(1024), 0, st, *r, d_type, f->S);
+    hipLaunchKernelGGL(k_fe_commit, g, dim3(64), 0, st, *f, d_setup, *r, d_dec);
+    hipLaunchKernelGGL(k_fe_blank, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, *r, d_packet_bytes, lanes);
     return CHECK_LAUNCH();
 }
 

@@ -27,5 +27,8 @@ int vbm_launch_untranspose_f32(const float *srcT, float *dst_bm, int rows, size_
 int vbm_launch_untranspose_i32(const int *srcT, int *dst_bm, int rows, size_t slab, int ncols, hipStream_t st);
 // packet rows -> one byte run per packet at 4-byte aligned offsets (off[n+1], exclusive scan of the padded lengths)
 int vbm_launch_compact(const uint8_t *rows, const int *len, int n, int maxb, long long *off, uint8_t *out, hipStream_t q);
+// the same with a device-resident column count (NULL: ncols), and a plain int copy of the first *d_count (or n) entries
+int vbm_launch_untranspose_counted(const int *srcT, int *dst_bm, int rows, size_t slab, int ncols, const int *d_ncols, hipStream_t st);
+int vbm_launch_copy_counted(int *dst, const int *src, int n, const int *d_count, hipStream_t st);
 int vbm_launch_untranspose_u8(const uint8_t *srcT, uint8_t *dst_bm, int rows, size_t slab, int ncols, hipStream_t st);
 }

@@ -20,9 +20,10 @@ extern "C" int vbm_launch_window_mdct(const float *d_pcm, float *d_out, const ui
                                       const float *d_trig, const float *d_win_self,
                                       const float *d_win_short, int n, int short_n,
                                       int apply_window, long nblocks, int max_workgroups,
+                                      const int *d_live, int live_mult,   // NULL, or device count: *d_live * live_mult blocks exist
                                       hipStream_t stream);
 
 extern "C" int vbm_launch_window_fft_log(const float *d_pcm, float *d_logfft, float *d_local_ampmax,
                                          const uint8_t *d_wflags, const float *d_wa, const float *d_win_self,
                                          const float *d_win_short, int n, int short_n, long nblocks,
-                                         hipStream_t stream);
+                                         const int *d_live, int live_mult, hipStream_t stream);

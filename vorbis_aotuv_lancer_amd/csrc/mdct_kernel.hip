@@ -294,8 +294,13 @@ void k_window_mdct(const float *__restrict__ pcm, float *__restrict__ out,
                    const float *__restrict__ win_self,  // rising half-window of size N   (N/2 floats)
                    const float *__restrict__ win_short, // rising half-window of the short size (short_n/2 floats), N == 2048 only
                    int short_n, int apply_window,       // 0 none, 1 Vorbis window (lW/nW shapes), 2 = win_self is a full N-sample table
-                   long nblocks, vbm_ve_gather gather)
+                   long nblocks, vbm_ve_gather gather,
+                   const int *__restrict__ d_live, int live_mult)   // device-resident count: only *d_live * live_mult blocks exist
 {
+    if (d_live) {
+        const long live = (long)*d_live * live_mult;
+        if (live < nblocks) nblocks = live;
+    }
     using G = Geo<N>;
     constexpr int C = G::C;
     constexpr int NTRIG = N + N / 4;
@@ -432,8 +437,13 @@ void k_window_mdct(const float *__restrict__ pcm, float *__restrict__ out,
 __global__ __launch_bounds__(64 * WAVES_PER_WG)
 void k_window_mdct_4096(const float *__restrict__ pcm, float *__restrict__ out, const uint8_t *__restrict__ wflags,
                         const float *__restrict__ trig_g, const float *__restrict__ win_self,
-                        const float *__restrict__ win_short, int short_n, int apply_window, long nblocks)
+                        const float *__restrict__ win_short, int short_n, int apply_window, long nblocks,
+                        const int *__restrict__ d_live, int live_mult)
 {
+    if (d_live) {
+        const long live = (long)*d_live * live_mult;
+        if (live < nblocks) nblocks = live;
+    }
     constexpr int N = 4096, C = 1024, R1 = N / 16, R2 = 3 * N / 16, NTRIG = N + N / 4;
     __shared__ __attribute__((aligned(16))) float s_trig[NTRIG];
     __shared__ __attribute__((aligned(16))) float s_win[N / 2];
@@ -544,7 +554,7 @@ extern "C" int vbm_launch_window_mdct(const float *d_pcm, float *d_out, const ui
                                       const float *d_trig, const float *d_win_self,
                                       const float *d_win_short, int n, int short_n,
                                       int apply_window, long nblocks, int max_workgroups,
-                                      hipStream_t stream)
+                                      const int *d_live, int live_mult, hipStream_t stream)
 {
     if (nblocks <= 0) return 0;
     if (n == 4096) {
@@ -552,7 +562,7 @@ extern "C" int vbm_launch_window_mdct(const float *d_pcm, float *d_out, const ui
         if (max_workgroups <= 0) max_workgroups = 256 * 4;
         if (wgs4 > max_workgroups) wgs4 = max_workgroups;
         hipLaunchKernelGGL(k_window_mdct_4096, dim3((unsigned)wgs4), dim3(64 * WAVES_PER_WG), 0, stream, d_pcm, d_out,
-                           d_wflags, d_trig, d_win_self, d_win_short, short_n, apply_window, nblocks);
+                           d_wflags, d_trig, d_win_self, d_win_short, short_n, apply_window, nblocks, d_live, live_mult);
         return hipGetLastError() == hipSuccess ? 0 : -2;
     }
     if (n != 2048 && n != 1024 && n != 512 && n != 256) return -1;
@@ -565,7 +575,7 @@ extern "C" int vbm_launch_window_mdct(const float *d_pcm, float *d_out, const ui
     dim3 grid((unsigned)wgs), block(64 * WAVES_PER_WG);
 #define LAUNCH_MDCT(NN)                                                                                        \
     hipLaunchKernelGGL(k_window_mdct<NN>, grid, block, 0, stream, d_pcm, d_out, d_wflags, d_trig, d_win_self, \
-                       d_win_short, short_n, apply_window, nblocks, none)
+                       d_win_short, short_n, apply_window, nblocks, none, d_live, live_mult)
     if (n == 2048) LAUNCH_MDCT(2048);
     else if (n == 1024) LAUNCH_MDCT(1024);
     else if (n == 512) LAUNCH_MDCT(512);
@@ -584,6 +594,6 @@ extern "C" int vbm_launch_ve_mdct(const vbm_ve_gather *g, float *d_out, const fl
     long wgs = (ngroups + WAVES_PER_WG - 1) / WAVES_PER_WG;
     if (wgs > 256 * 8) wgs = 256 * 8;
     hipLaunchKernelGGL((k_window_mdct<128, true>), dim3((unsigned)wgs), dim3(64 * WAVES_PER_WG), 0, stream, g->pcm, d_out,
-                       (const uint8_t *)nullptr, d_trig, d_win, (const float *)nullptr, 0, 2, nblocks, *g);
+                       (const uint8_t *)nullptr, d_trig, d_win, (const float *)nullptr, 0, 2, nblocks, *g, (const int *)nullptr, 0);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

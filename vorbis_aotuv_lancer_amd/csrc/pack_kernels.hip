@@ -234,7 +234,7 @@ __device__ __forceinline__ res_view residue_view(const vbm_batch &b, const vbm_m
 __global__ void k_nonzero_propagate(vbm_batch b)
 {
     const int sb = blockIdx.x * blockDim.x + threadIdx.x;
-    if (sb >= b.nsb) return;
+    if (sb >= vbm_nsb(b)) return;
     const vbm_map *info = &b.setup->map[b.W];
     const size_t col0 = (size_t)sb * b.ch;
     for (int i = 0; i < info->coupling_steps; i++) {
@@ -250,7 +250,7 @@ __global__ void k_nonzero_propagate(vbm_batch b)
 __global__ void k_pack_head(vbm_batch b)
 {
     const int sb = blockIdx.x * blockDim.x + threadIdx.x;
-    if (sb >= b.nsb) return;
+    if (sb >= vbm_nsb(b)) return;
     const size_t SW = b.slab_words;
     const vbm_setup *s = b.setup;
     const vbm_map *info = &s->map[b.W];
@@ -357,7 +357,7 @@ __global__ void k_pack_head(vbm_batch b)
 __global__ void k_block_state(vbm_batch b, int reps)
 {
     const int sb = blockIdx.x * blockDim.x + threadIdx.x;
-    if (sb >= b.nsb) return;
+    if (sb >= vbm_nsb(b)) return;
     const int sid = b.stream_id[sb];
     const int block_mode = b.block_mode;
     int impadnum = b.st.impadnum[sid];
@@ -382,7 +382,7 @@ __global__ void k_block_state(vbm_batch b, int reps)
 __global__ void k_bitrate_choose(vbm_batch b)
 {
     const int sb = blockIdx.x * blockDim.x + threadIdx.x;
-    if (sb >= b.nsb) return;
+    if (sb >= vbm_nsb(b)) return;
     const vbm_setup *s = b.setup;
     const int sid = b.stream_id[sb];
     const int *__restrict__ sizes = b.packet_bytes_blob + sb;      // blob k at [k * Ls]
@@ -512,7 +512,7 @@ __global__ void k_blob_gather(vbm_batch b, uint32_t *__restrict__ dst)
     const size_t blob_stride = (size_t)b.Ls * b.max_packet_bytes;   // bytes per blob
     {
         const int c = c0 + tx;
-        const bool live = c < b.nsb;
+        const bool live = c < vbm_nsb(b);
         const int k = live ? b.choice[c] : 0;
         const int len = live ? b.packet_bytes[c] : 0;
         const uint32_t *src = (const uint32_t *)(b.packetT_blob + (size_t)k * blob_stride) + (size_t)(c >> 6) * rows * 64 + (c & 63);
@@ -530,7 +530,7 @@ __global__ void k_blob_gather(vbm_batch b, uint32_t *__restrict__ dst)
     __syncthreads();
     for (int cc = ty; cc < 64; cc += 4) {
         const int c = c0 + cc, r = r0 + tx;
-        if (c < b.nsb && r < rows) dst[(size_t)c * rows + r] = tile[tx][cc];
+        if (c < vbm_nsb(b) && r < rows) dst[(size_t)c * rows + r] = tile[tx][cc];
     }
 }
 
@@ -587,7 +587,7 @@ __global__ void k_res_vq(vbm_batch b, int sm, int nchunks)
 {
     extern __shared__ int vq_lds[];   // [samples per partition][64 lanes]
     const int sb = blockIdx.x * blockDim.x + threadIdx.x;
-    if (sb >= b.nsb) return;
+    if (sb >= vbm_nsb(b)) return;
     const vbm_setup *s = b.setup;
     const vbm_map *info = &s->map[b.W];
     const size_t col0 = (size_t)sb * b.ch;
@@ -656,7 +656,7 @@ __global__ void k_res_vq(vbm_batch b, int sm, int nchunks)
 __global__ void k_res_offsets(vbm_batch b, int sm)
 {
     const int sb = blockIdx.x * blockDim.x + threadIdx.x;
-    if (sb >= b.nsb) return;
+    if (sb >= vbm_nsb(b)) return;
     const vbm_setup *s = b.setup;
     const vbm_map *info = &s->map[b.W];
     const size_t col0 = (size_t)sb * b.ch;
@@ -745,7 +745,7 @@ __global__ void k_res_offsets(vbm_batch b, int sm)
 __global__ void k_res_emit(vbm_batch b, int sm, int nchunks)
 {
     const int sb = blockIdx.x * blockDim.x + threadIdx.x;
-    if (sb >= b.nsb) return;
+    if (sb >= vbm_nsb(b)) return;
     const vbm_map *info = &b.setup->map[b.W];
     const size_t col0 = (size_t)sb * b.ch;
     const res_view v = residue_view(b, info, sm, col0);

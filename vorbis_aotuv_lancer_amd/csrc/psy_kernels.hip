@@ -44,7 +44,7 @@ __device__ __forceinline__ const vbm_psy *psy_of(const vbm_batch &b)
 __global__ void k_prologue(vbm_batch b)
 {
     const int sb = blockIdx.x * blockDim.x + threadIdx.x;
-    if (sb >= b.nsb) return;
+    if (sb >= vbm_nsb(b)) return;
     const vbm_setup *s = b.setup;
     const int sid = b.stream_id[sb];
     // vorbis_analysis_blockout, lib/block.c:649-651
@@ -233,7 +233,7 @@ template <int PASS>
 __global__ void k_nm_prefix(vbm_batch b)
 {
     const int lane = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lane >= b.ncb) return;
+    if (lane >= vbm_ncb(b)) return;
     const size_t tb = TB(b, lane);
     const vbm_psy *p = psy_of(b);
     const int sb = lane / b.ch, c = lane - sb * b.ch;
@@ -321,7 +321,7 @@ template <int PASS>
 __global__ void k_nm_solve(vbm_batch b, int nchunks)
 {
     const int lane = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lane >= b.ncb) return;
+    if (lane >= vbm_ncb(b)) return;
     const size_t tb = TB(b, lane);
     const vbm_psy *p = psy_of(b);
     const int n = p->n;
@@ -488,14 +488,14 @@ __device__ __forceinline__ void ntfix(const vbm_batch &b, const vbm_psy *p, int 
 __global__ void k_nm_ntfix(vbm_batch b)
 {
     const int lane = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lane >= b.ncb) return;
+    if (lane >= vbm_ncb(b)) return;
     ntfix(b, psy_of(b), lane, b.logmdctT, b.logmaskT);   // pass 2's logmdct - work: see k_nm_solve
 }
 
 __global__ void k_nm_post(vbm_batch b, int nchunks)
 {
     const int lane = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lane >= b.ncb) return;
+    if (lane >= vbm_ncb(b)) return;
     const size_t tb = TB(b, lane);
     const vbm_setup *s = b.setup;
     const vbm_psy *p = psy_of(b);
@@ -956,7 +956,7 @@ __global__ void k_mix(vbm_batch b, int nchunks)
     __shared__ uint8_t colact[64];
     const int lane = blockIdx.x * blockDim.x + threadIdx.x;
     // managed bitrate: the hi / lo rate passes run only for channels whose first fit exists (lib/mapping0.c:1097)
-    const bool active = lane < b.ncb && !(MANAGED && SEL != 1 && !b.post_valid_blob[(size_t)(VBM_PACKETBLOBS / 2) * b.L + lane]);
+    const bool active = lane < vbm_ncb(b) && !(MANAGED && SEL != 1 && !b.post_valid_blob[(size_t)(VBM_PACKETBLOBS / 2) * b.L + lane]);
     __shared__ int s_bfn[M0 ? 256 : 1];
     if (M0) {
         const int *g = (b.n == 128) ? b.setup->freq_bfn128 : b.setup->freq_bfn256;

@@ -230,7 +230,7 @@ __device__ __forceinline__ float noise_normalize(const nn_consts *p, const int l
 __global__ void k_couple_m6stats(vbm_batch b)
 {
     const int sb = blockIdx.x * blockDim.x + threadIdx.x;
-    if (sb >= b.nsb) return;
+    if (sb >= vbm_nsb(b)) return;
     const size_t SW = b.slab_words;
     const vbm_setup *s = b.setup;
     const vbm_psy *p = &s->psy[b.block_mode];
@@ -280,7 +280,7 @@ __global__ void k_couple_m6stats(vbm_batch b)
 __global__ void k_couple_quantize(vbm_batch b, int nchunks)
 {
     const int sb = blockIdx.x * blockDim.x + threadIdx.x;
-    if (sb >= b.nsb) return;
+    if (sb >= vbm_nsb(b)) return;
     const size_t SW = b.slab_words;
     const vbm_setup *s = b.setup;
     const vbm_psy *p = &s->psy[b.block_mode];
@@ -719,7 +719,7 @@ __global__ __launch_bounds__(FP * FPC) void k_couple_fast(vbm_batch b)
         c.lowpassr = lowpassr;
     }
     const float *__restrict__ fromdB = s->fromdB;
-    const int ncols = (MODE == 1) ? b.nsb : b.ncb;
+    const int ncols = (MODE == 1) ? vbm_nsb(b) : vbm_ncb(b);
     const int pi = blockIdx.y, i = pi * FP;
     const int tid = threadIdx.x;
 

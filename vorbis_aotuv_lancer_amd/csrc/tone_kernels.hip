@@ -113,7 +113,7 @@ __global__ __launch_bounds__(TM_NB * 32) void k_tonemask(vbm_batch b, const int 
     unsigned short *glS = (unsigned short *)(tm_lds + TM_NB * tnp + (TM_NB & 1));   // [NB][glp]
     const int tid = threadIdx.x;
     const int cb0 = blockIdx.x * TM_NB;
-    const int nblk = (b.ncb - cb0 < TM_NB) ? b.ncb - cb0 : TM_NB;
+    const int nblk = (vbm_ncb(b) - cb0 < TM_NB) ? vbm_ncb(b) - cb0 : TM_NB;
 
     for (int k = tid; k < TM_NB * tnp; k += TM_THREADS) seedK[k] = seed_key(NEGINF);
     if (tid < TM_NB) {

@@ -29,8 +29,11 @@ __global__ void k_to_tiled(const T *__restrict__ src, T *__restrict__ dst, int n
 
 // tiled src -> block-major dst[c][r]
 template <typename T>
-__global__ void k_from_tiled(const T *__restrict__ src, T *__restrict__ dst, int ncols, int rows, size_t slab)
+__global__ void k_from_tiled(const T *__restrict__ src, T *__restrict__ dst, int ncols, int rows, size_t slab,
+                             const int *__restrict__ d_ncols)
 {
+    if (d_ncols) ncols = *d_ncols;                 // device-resident count: `ncols` was the launch bound
+    if ((int)(blockIdx.x * 64) >= ncols) return;
     __shared__ T tile[64][65];
     const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -43,6 +46,13 @@ __global__ void k_from_tiled(const T *__restrict__ src, T *__restrict__ dst, int
         int c = c0 + cc, r = r0 + tx;
         if (c < ncols && r < rows) dst[(size_t)c * rows + r] = tile[tx][cc];
     }
+}
+
+__global__ void k_copy_counted(int *__restrict__ dst, const int *__restrict__ src, int n, const int *__restrict__ d_count)
+{
+    if (d_count) n = *d_count;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
 }
 
 __global__ void k_spread_flags(const uint8_t *__restrict__ wflags, uint8_t *__restrict__ wflags_cb, int nsb, int ch)
@@ -60,10 +70,10 @@ int to_tiled(const T *src, T *dst, int ncols, int rows, size_t slab, hipStream_t
 }
 
 template <typename T>
-int from_tiled(const T *src, T *dst, int ncols, int rows, size_t slab, hipStream_t st)
+int from_tiled(const T *src, T *dst, int ncols, int rows, size_t slab, hipStream_t st, const int *d_ncols = nullptr)
 {
     dim3 grid((unsigned)((ncols + 63) / 64), (unsigned)((rows + 63) / 64));
-    hipLaunchKernelGGL(k_from_tiled<T>, grid, dim3(256), 0, st, src, dst, ncols, rows, slab);
+    hipLaunchKernelGGL(k_from_tiled<T>, grid, dim3(256), 0, st, src, dst, ncols, rows, slab, d_ncols);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -176,6 +186,17 @@ extern "C" int vbm_launch_untranspose_i32(const int *srcT, int *dst_bm, int rows
                                           hipStream_t st)
 {
     return from_tiled<int>(srcT, dst_bm, ncols, rows, slab, st);
+}
+extern "C" int vbm_launch_untranspose_counted(const int *srcT, int *dst_bm, int rows, size_t slab, int ncols,
+                                              const int *d_ncols, hipStream_t st)
+{
+    return from_tiled<int>(srcT, dst_bm, ncols, rows, slab, st, d_ncols);
+}
+extern "C" int vbm_launch_copy_counted(int *dst, const int *src, int n, const int *d_count, hipStream_t st)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_copy_counted, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dst, src, n, d_count);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 extern "C" int vbm_launch_untranspose_u8(const uint8_t *srcT, uint8_t *dst_bm, int rows, size_t slab, int ncols,
                                          hipStream_t st)

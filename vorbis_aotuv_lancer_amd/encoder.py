@@ -262,8 +262,51 @@ class FrontEnd:
         k = sum(counts)
         return self._ring_views[at][:k], packets[:k], nbytes[:k], counts
 
+    @property
+    def device_lanes(self):
+        """output slots of one device-built round (vbm_device_round_lanes): the Encoder needs max_batch >= this"""
+        return lib.vbm_device_round_lanes(self.enc.setup._h, self.enc.nstreams)
+
+    def encode_rounds_device(self, nrounds=2, lazy=False, device=None):
+        """vbm_frontend_encode_rounds_device: `nrounds` rounds built and run on the device, nothing read back.
+        Returns device tensors (info uint8 [nrounds * lanes, 40] = vbm_packet_info records, packets uint8
+        [nrounds * lanes, max_bytes], nbytes int32 [nrounds * lanes] with -2 = empty lane, counts int32 [nrounds, 4]),
+        complete on the current stream when the call's work has run (lazy: the call's long-block batch one call
+        later).  They live in a ring of three sets owned by this object."""
+        dev = device or torch.device("cuda", torch.cuda.current_device())
+        lanes = self.device_lanes
+        ring = getattr(self, "_dring", None)
+        if ring is None or self._dring_key != (nrounds, dev):
+            if ring is not None:
+                self.join()
+                torch.cuda.synchronize(dev)
+            n = nrounds * lanes
+            self._dring = [(torch.zeros((n, C.sizeof(PacketInfo)), dtype=torch.uint8, device=dev),
+                            torch.empty((n, self.enc.max_packet_bytes), dtype=torch.uint8, device=dev),
+                            torch.full((n,), -2, dtype=torch.int32, device=dev),
+                            torch.zeros((nrounds, 4), dtype=torch.int32, device=dev)) for _ in range(3)]
+            self._dring_key, self._dring_at = (nrounds, dev), 0
+        at = self._dring_at
+        self._dring_at = (at + 1) % 3
+        info, packets, nbytes, counts = self._dring[at]
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(lib.vbm_frontend_encode_rounds_device(self._h, nrounds, packets.data_ptr(), nbytes.data_ptr(), info.data_ptr(),
+                                                    counts.data_ptr(), 1 if lazy else 0, st),
+              "vbm_frontend_encode_rounds_device")
+        return info, packets, nbytes, counts
+
+    def device_stats(self):
+        """running totals of the device-built rounds: ([blocks of type 0..3], samples all streams advanced by)"""
+        out = (C.c_ulonglong * 5)()
+        check(lib.vbm_frontend_device_stats(self._h, out), "vbm_frontend_device_stats")
+        return [int(out[k]) for k in range(4)], int(out[4])
+
     def close(self):
         if self._h:
+            if getattr(self, "_dring", None) is not None:
+                self.join()
+                torch.cuda.synchronize(self._dring_key[1])
+                self._dring = None
             if getattr(self, "_ring", None) is not None:      # nothing may still be writing the ring
                 self.join()
                 torch.cuda.synchronize(self._ring_dev)
