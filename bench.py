@@ -230,7 +230,7 @@ def main():
 
     setup = v.Setup(CHANNELS, RATE, bitrate=args.bitrate) if args.bitrate else v.Setup(CHANNELS, RATE, QUALITY)
     S = hi - lo
-    enc = v.Encoder(setup, S)
+    enc = v.Encoder(setup, S, max_batch=max(S, v.lib.vbm_device_round_lanes(setup._h, S)))
     params = stream_params(torch, dev, lo, hi)
     ncb = S * CHANNELS
     traffic, traffic_src = load_traffic(ncb)
@@ -269,8 +269,16 @@ def main():
         kept = []
         counting = [False]
 
+        DEVICE_ROUNDS = os.environ.get("VBM_BENCH_DEVICE_ROUNDS", "1") != "0"
+        NROUNDS = int(os.environ.get("VBM_BENCH_ROUNDS", "2"))
+
         def step_pcm(k):
             fe.write(chunks[k])
+            if DEVICE_ROUNDS:
+                # rounds built on the device: the call only enqueues (no decision ever comes back to the host)
+                kept.append(fe.encode_rounds_device(nrounds=NROUNDS, lazy=LAZY_JOIN, device=dev))
+                del kept[:-3]
+                return
             info, pk_, nb_, counts = fe.encode_rounds(min_rounds=MIN_ROUNDS, max_rounds=16, headroom=HOP, device=dev,
                                                       lazy=LAZY_JOIN)
             if counting[0] and len(info):
@@ -283,28 +291,56 @@ def main():
             kept.append((info, pk_, nb_))     # lazy: the outputs of a call are complete after the next one
             del kept[:-3]
 
+        base_stats = [None]
+
         def count_from_now():
             fe.join()
             counting[0] = True
+            if DEVICE_ROUNDS:
+                base_stats[0] = fe.device_stats()
 
         # warmup is not counted; the timed region starts with a join so that nothing of it is left pending
+        PROF_STEPS = 8
+        nsteps_total = args.warmup + args.steps + PROF_STEPS
+        while len(chunks) < nsteps_total:
+            chunks.append(synth_pcm(torch, dev, params, gen, len(chunks) * HOP, HOP))
         for k in range(args.warmup):
             step_pcm(k)
         count_from_now()
         barrier()
-        enc.profile_begin(args.steps * 4)
         t0 = time.perf_counter()
         for k in range(args.steps):
             step_pcm(args.warmup + k)
         fe.join()
         barrier()
         dt_local = time.perf_counter() - t0
+        end_stats = fe.device_stats() if DEVICE_ROUNDS else None
+        # stage times: a few more steps with HIP events between the stage kernels (outside the timed region: the
+        # device-built rounds run as HIP graphs, which have no room for events; with timing on they are launched
+        # kernel by kernel)
+        enc.profile_begin(PROF_STEPS * 4)
+        for k in range(PROF_STEPS):
+            step_pcm(args.warmup + args.steps + k)
+        fe.join()
+        torch.cuda.synchronize()
         blocks_prof = int(v.lib.vbm_encoder_profile_blocks(enc._h))
         stage_ms, calls = enc.profile_end()
-        nb_last = kept[-1][2]
-        stat["mean_bytes"] = float(nb_last.float().mean().item()) if len(nb_last) else 0.0
+        if DEVICE_ROUNDS:
+            modes1, samples1 = end_stats               # totals kept on the device: (blocks per type, samples advanced)
+            modes0, samples0 = base_stats[0]
+            stat["modes"] = np.array([a - b for a, b in zip(modes1, modes0)], np.int64)
+            stat["blocks"] = int(stat["modes"].sum())
+            stat["samples"] = samples1 - samples0
+            stat["rounds"] = NROUNDS * args.steps
+            nb_last = kept[-1][2]
+            live = nb_last[nb_last >= 0]
+            stat["mean_bytes"] = float(live.float().mean().item()) if len(live) else 0.0
+            stat["max_buffered_end"] = fe.max_buffered
+        else:
+            nb_last = kept[-1][2]
+            stat["mean_bytes"] = float(nb_last.float().mean().item()) if len(nb_last) else 0.0
         results["pcm"] = dict(dt_local=dt_local, stage_ms=stage_ms, calls=calls, blocks_prof=blocks_prof, stat=stat,
-                              audio_local=stat["samples"] / RATE)
+                              audio_local=stat["samples"] / RATE, prof_steps=PROF_STEPS)
         fe.close()
         del chunks, kept
 
@@ -351,7 +387,7 @@ def main():
     if rank == 0:
         def stage_view(r):
             calls = max(r["calls"], 1)
-            per_step = {k: ms_ / args.steps for k, ms_ in r["stage_ms"].items()}
+            per_step = {k: ms_ / r.get("prof_steps", args.steps) for k, ms_ in r["stage_ms"].items()}
             per_launch = {k: ms_ / calls for k, ms_ in r["stage_ms"].items()}
             cb = r["blocks_prof"] * CHANNELS // calls if r["blocks_prof"] else ncb   # channel-blocks per timed launch
             dominant = max(per_step, key=per_step.get)
@@ -407,6 +443,9 @@ def main():
                 "input_audio_s_per_rank": S * HOP / RATE * args.steps,
                 "encoded_audio_s_rank0": results["pcm"]["audio_local"],
                 "mean_packet_bytes_last_call": st["mean_bytes"],
+                "rounds_built_on": "device (no host synchronisation inside the timed region)" if st.get("max_buffered_end") is not None
+                                   else "host (one synchronisation per round)",
+                "max_buffered_samples_at_end": st.get("max_buffered_end"),
             })
         if "block" in results:
             B = results["block"]

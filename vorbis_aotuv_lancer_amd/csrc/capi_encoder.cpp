@@ -93,6 +93,21 @@ struct vbm_encoder {
     int lazy_w = -1, lazy_m = -1;   // the newest big batch (the one a lazy join leaves pending)
     int round_w = -1;                      // workspace of the newest round
     int call_big_w = -1;                   // rounds built on the device: workspace of the current call's big batch
+    // ... run as HIP graphs: the ~180 launches of a round cost the host more than the round costs the device, and
+    // with device-resident counts every launch of a round has the same arguments each time its workspace comes up.
+    // Three in-order streams: gq[0] all small batches of all rounds, gq[1] the front halves of the big (first round,
+    // long blocks) batches, gq[2] their back halves.  A group = the launches of one of them for one workspace,
+    // captured the second time it is needed and replayed from then on.
+    struct round_graph { hipGraphExec_t exec = nullptr; int uses = 0; };
+    round_graph gJ[kMaxWS][4][3];          // [workspace][block type][0 whole pipeline, 1 front half, 2 back half]
+    hipEvent_t ev_state_big[kMaxWS] = {};  // front half of the big batch run in the workspace
+    int queue_last_w[4] = {-1, -1, -1, -1};   // workspace of the newest job on sub[0..3]
+    int prev_call_big_w = -1;
+    bool small_streams_set = false;
+    hipEvent_t ev_cap_fork = nullptr, ev_cap_join[4] = {};
+    int *d_counts_ws = nullptr;            // [kMaxWS][4] block counts of the round in each workspace
+    int use_graphs = -1;
+    int device_mode = 0;                   // how the last device-built round ran: 1 graphs, 2 plain launches
     bool device_rounds = false;            // ... have run: the per-stream bookkeeping below knows nothing of them
     // the tone-mask branch of a slice runs on its own stream beside the noise-mask branch
     bool overlap_branches = true;
@@ -148,6 +163,15 @@ extern "C" void vbm_encoder_destroy(vbm_encoder *e)
 {
     if (!e) return;
     for (void *p : e->allocs) (void)hipFree(p);
+    for (int i = 0; i < kMaxWS; i++) {
+        for (int m = 0; m < 4; m++)
+            for (int k = 0; k < 3; k++)
+                if (e->gJ[i][m][k].exec) (void)hipGraphExecDestroy(e->gJ[i][m][k].exec);
+        if (e->ev_state_big[i]) (void)hipEventDestroy(e->ev_state_big[i]);
+    }
+    if (e->ev_cap_fork) (void)hipEventDestroy(e->ev_cap_fork);
+    for (int i = 0; i < 4; i++)
+        if (e->ev_cap_join[i]) (void)hipEventDestroy(e->ev_cap_join[i]);
     for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : e->ev_join) (void)hipEventDestroy(ev);
     for (hipStream_t q : e->sub) (void)hipStreamDestroy(q);
@@ -360,7 +384,8 @@ extern "C" int vbm_encoder_create(vbm_encoder **out, vbm_setup_handle *setup, in
     for (int i = 0; i < kMaxWS; i++)
         for (int m = 0; m < 4; m++)
             if (hipEventCreateWithFlags(&e->ev_done[i][m], hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&e->ev_state[i][m], hipEventDisableTiming) != hipSuccess) {
+                hipEventCreateWithFlags(&e->ev_state[i][m], hipEventDisableTiming) != hipSuccess ||
+                (m == 0 && hipEventCreateWithFlags(&e->ev_state_big[i], hipEventDisableTiming) != hipSuccess)) {
                 vbm_encoder_destroy(e);
                 return VBM_EHIP;
             }
@@ -785,6 +810,11 @@ struct type_job {
     int *d_packet_bytes;
     bool big, timed;
     unsigned depmask;            // bit (ww * 4 + t): slot (ww, t) holds a batch this one's streams may come from
+    // rounds run as graphs (device_round_run_graphs): the job is one piece of a group that is forked from / joined
+    // to its origin stream by the caller, in or outside a stream capture
+    int part = 0;                // 0 whole pipeline, 1 front half only (up to the block-state update), 2 back half only
+    bool grouped = false;        // no ev_fork wait, no dependency waits, no state / done events, no output copy
+    hipStream_t q_on = nullptr;  // grouped: the stream to enqueue on
 };
 
 static int enqueue_job(vbm_encoder *e, const type_job &j)
@@ -793,9 +823,9 @@ static int enqueue_job(vbm_encoder *e, const type_job &j)
     hipError_t err;
     int rc = 0;
     const int m = j.m, w = j.w;
-    hipStream_t q = j.big ? e->sub[4] : e->sub[m];
+    hipStream_t q = j.grouped ? j.q_on : (j.big ? e->sub[4] : e->sub[m]);
     const int qid = j.big ? 4 : m;
-    if ((err = hipStreamWaitEvent(q, e->ev_fork, 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
+    if (!j.grouped && (err = hipStreamWaitEvent(q, e->ev_fork, 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
     vbm_batch full;
     configure(e, full, m, j.bound, j.pcm, w);
     vbm_batch v = slice_of(full, j.lane0, j.bound);
@@ -805,6 +835,7 @@ static int enqueue_job(vbm_encoder *e, const type_job &j)
     const bool pr = j.timed;
 #define RUN(x) do { rc = (x); if (rc) { g_vbm_err = std::string("launch failed: ") + #x; return VBM_EHIP; } } while (0)
 #define TIMED(k, qq) stage_scope scope_##k(e, pr, k, qq)
+    if (j.part != 2) {
     RUN(vbm_launch_spread_flags(&v, q));
     { TIMED(0, q);
       RUN(vbm_launch_window_mdct(v.pcm, v.mdct_bm, W ? v.wflags_cb : nullptr, vbm_setup_device_ptrs(e->H)->mdct_trig[W],
@@ -817,6 +848,7 @@ static int enqueue_job(vbm_encoder *e, const type_job &j)
     { TIMED(2, q); RUN(vbm_launch_transpose_in(&v, q)); }
     // the transforms above read the block's PCM only; from here on the carried stream state is involved: the
     // batches this batch's streams were last part of come first (those on this very HIP stream already do)
+    if (!j.grouped)
     for (int ww = 0; ww < e->nws; ww++)
         for (int t = 0; t < 4; t++)
             if (((j.depmask >> (ww * 4 + t)) & 1u) && (e->slot_queue[ww][t] != qid || s->managed) &&
@@ -828,11 +860,15 @@ static int enqueue_job(vbm_encoder *e, const type_job &j)
     { TIMED(6, q);
       if (s->managed) RUN(managed_front(v, q));
       else { RUN(vbm_launch_mix(&v, q)); RUN(vbm_launch_block_state(&v, q)); } }
+    }   // part != 2
+    if (j.part == 1) return VBM_OK;
+    if (!j.grouped) {
     if ((err = hipEventRecord(e->ev_state[w][m], q)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
     if (j.big) {   // hand over to the back-half stream of big batches
         if ((err = hipStreamWaitEvent(e->sub[5], e->ev_state[w][m], 0)) != hipSuccess)
             return vbm_set_hip_error(err, "big batch hand-over");
         q = e->sub[5];
+    }
     }
     if (s->managed) {
         TIMED(10, q);
@@ -843,16 +879,33 @@ static int enqueue_job(vbm_encoder *e, const type_job &j)
         { TIMED(9, q); RUN(vbm_launch_couple_quantize(&v, q)); }
         { TIMED(10, q); RUN(vbm_launch_pack(&v, q)); }
     }
+    if (j.grouped) return VBM_OK;     // the group's caller copies the outputs and records the events
     { TIMED(11, q);
       if (j.d_packets && !s->managed)
           RUN(vbm_launch_untranspose_counted((const int *)v.packetT, (int *)j.d_packets, e->max_packet_bytes / 4,
                                              (size_t)(e->max_packet_bytes / 4) * 64, v.nsb, v.d_nsb, q));
       if (j.d_packet_bytes) RUN(vbm_launch_copy_counted(j.d_packet_bytes, v.packet_bytes, v.nsb, v.d_nsb, q)); }
 #undef TIMED
-#undef RUN
     if ((err = hipEventRecord(e->ev_done[w][m], q)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
     return VBM_OK;
 }
+
+// outputs of one block type of workspace w to the caller's buffers (the tail of enqueue_job, for grouped jobs)
+static int copy_outputs(vbm_encoder *e, const type_job &j, hipStream_t q)
+{
+    int rc = 0;
+    vbm_batch full;
+    configure(e, full, j.m, j.bound, j.pcm, j.w);
+    vbm_batch v = slice_of(full, j.lane0, j.bound);
+    v.d_nsb = j.d_nsb;
+    if (e->hs->managed) return VBM_OK;   // (managed_back delivers the chosen packets itself)
+    if (j.d_packets)
+        RUN(vbm_launch_untranspose_counted((const int *)v.packetT, (int *)j.d_packets, e->max_packet_bytes / 4,
+                                           (size_t)(e->max_packet_bytes / 4) * 64, v.nsb, v.d_nsb, q));
+    if (j.d_packet_bytes) RUN(vbm_launch_copy_counted(j.d_packet_bytes, v.packet_bytes, v.nsb, v.d_nsb, q));
+    return VBM_OK;
+}
+#undef RUN
 
 // One round of blocks of all four block types: counts[m] blocks of type m, described by stream_ids /
 // wflags grouped by type (type 0 first); d_pcm: the blocks of type m start at float offset
@@ -1030,7 +1083,8 @@ static int analysis_round_impl(vbm_encoder *e, const int *counts, const int *str
 // d_count[m].  Order of a stream's blocks: the front end holds the streams of a call's first type-3 batch (the big
 // one) for the rest of the call, so a later round of the same call never holds a stream of it; every other batch
 // begun earlier may, and is waited for (its state event; a finished batch costs nothing).
-int vbm_encoder_device_round_open(vbm_encoder *e, hipStream_t fork, int *w_out, int **d_stream_id, uint8_t **d_wflags, int *lanes)
+int vbm_encoder_device_round_open(vbm_encoder *e, hipStream_t fork, int *w_out, int **d_stream_id, uint8_t **d_wflags, int *lanes,
+                                  int **d_counts)
 {
     int rc = vbm_encoder_set_sub_batches(e, e->nsplit);
     if (rc) return rc;
@@ -1041,6 +1095,25 @@ int vbm_encoder_device_round_open(vbm_encoder *e, hipStream_t fork, int *w_out, 
             hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return VBM_EHIP;
         e->sub.push_back(q);
         e->ev_join.push_back(ev);
+    }
+    if (!e->small_streams_set) {
+        // The small batches are chains of ~40 short kernels; beside the big batch every one of them queues behind
+        // its wide launches.  On high-priority streams their workgroups go first (they are few): the chain's
+        // latency is what the short-block runs of a stream wait for.  (VBM_SMALL_PRIORITY=0: plain streams.)
+        e->small_streams_set = true;
+        const char *env = getenv("VBM_SMALL_PRIORITY");
+        if (!env || atoi(env)) {
+            int lo = 0, hi = 0;
+            if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo)
+                for (int m = 0; m < 4; m++) {
+                    hipStream_t q;
+                    if (hipStreamCreateWithPriority(&q, hipStreamNonBlocking, hi) == hipSuccess) {
+                        (void)hipStreamSynchronize(e->sub[m]);
+                        (void)hipStreamDestroy(e->sub[m]);
+                        e->sub[m] = q;
+                    }
+                }
+        }
     }
     const int w = e->next;
     e->next = (e->next + 1) % e->nws;
@@ -1057,10 +1130,149 @@ int vbm_encoder_device_round_open(vbm_encoder *e, hipStream_t fork, int *w_out, 
         }
     e->last_ids[w].clear();
     e->last_flags[w].clear();
+    if (!e->d_counts_ws) {
+        if (hipMalloc((void **)&e->d_counts_ws, kMaxWS * 4 * sizeof(int)) != hipSuccess) return VBM_EHIP;
+        e->allocs.push_back(e->d_counts_ws);
+        (void)hipMemset(e->d_counts_ws, 0, kMaxWS * 4 * sizeof(int));
+    }
     *w_out = w;
     *d_stream_id = e->d_stream_id[w];
     *d_wflags = e->d_wflags[w];
     *lanes = e->Ls;
+    *d_counts = e->d_counts_ws + 4 * w;
+    return VBM_OK;
+}
+
+// A group of a round as a graph: `jobs` (grouped type_jobs) forked from and joined to `origin`; several jobs run side
+// by side on sub[job.m].  First use: plain launches (the launchers' one-time set-up runs then); second use: the
+// same calls under a stream capture, instantiated; from then on one hipGraphLaunch.
+static int run_group(vbm_encoder *e, vbm_encoder::round_graph &g, hipStream_t origin, type_job *jobs, int njobs, int kind = 0)
+{
+    hipError_t err;
+    static int mask = -1;
+    if (mask < 0) mask = getenv("VBM_GRAPH_MASK") ? atoi(getenv("VBM_GRAPH_MASK")) : 7;   // debugging: bit 0 small groups, 1 big front, 2 big back
+    if (g.exec) {
+        if ((err = hipGraphLaunch(g.exec, origin)) != hipSuccess) return vbm_set_hip_error(err, "hipGraphLaunch");
+        return VBM_OK;
+    }
+    const bool capture = e->use_graphs == 1 && g.uses >= 1 && ((mask >> kind) & 1);   // (use_graphs 2: the groups as plain launches, for A/B)
+    g.uses++;
+    if (capture && (err = hipStreamBeginCapture(origin, hipStreamCaptureModeThreadLocal)) != hipSuccess)
+        return vbm_set_hip_error(err, "hipStreamBeginCapture");
+    int rc = VBM_OK;
+    if (njobs == 1) {
+        jobs[0].q_on = origin;
+        rc = enqueue_job(e, jobs[0]);
+    } else {
+        if ((err = hipEventRecord(e->ev_cap_fork, origin)) != hipSuccess) rc = vbm_set_hip_error(err, "hipEventRecord");
+        for (int k = 0; k < njobs && !rc; k++) {
+            hipStream_t q = e->sub[jobs[k].m];
+            jobs[k].q_on = q;
+            if ((err = hipStreamWaitEvent(q, e->ev_cap_fork, 0)) != hipSuccess) { rc = vbm_set_hip_error(err, "hipStreamWaitEvent"); break; }
+            rc = enqueue_job(e, jobs[k]);
+            if (rc) break;
+            if ((err = hipEventRecord(e->ev_cap_join[jobs[k].m], q)) != hipSuccess ||
+                (err = hipStreamWaitEvent(origin, e->ev_cap_join[jobs[k].m], 0)) != hipSuccess)
+                rc = vbm_set_hip_error(err, "group join");
+        }
+    }
+    if (capture) {
+        hipGraph_t graph = nullptr;
+        err = hipStreamEndCapture(origin, &graph);
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (err != hipSuccess) return vbm_set_hip_error(err, "hipStreamEndCapture");
+        err = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (err != hipSuccess) { g.exec = nullptr; return vbm_set_hip_error(err, "hipGraphInstantiate"); }
+        if ((err = hipGraphLaunch(g.exec, origin)) != hipSuccess) return vbm_set_hip_error(err, "hipGraphLaunch");
+    }
+    return rc;
+}
+
+// Device-built round with every job's launches replayed as a HIP graph.  Streams as in the plain form: sub[m] takes the
+// small batches of block type m of all rounds, in order; sub[4] the front halves of the big (first round, long
+// blocks) batches, sub[5] their back halves.  What a job waits for besides its own stream is decided by the block
+// types alone (lib/block.c:620-638: a long block with both neighbours long is type 3, with a short neighbour type 2;
+// short blocks are 0 / 1): a stream's consecutive blocks go 3->3, 3->2, 2->3, 2->2, 2->0/1, 0/1->0/1, 0/1->2, so
+// types 0 / 1 never follow type 3 directly and type 3 never follows them: short batches and long batches only meet
+// through the transition batches.  A job waits for the newest state event of every type it may follow, as they stood
+// before the round's own jobs went in — and, since the front end holds the streams of a call's big batch for the rest
+// of the call, never for the big batch of its own call.
+static int device_round_run_graphs(vbm_encoder *e, int w, const int *lane0, const int *cap, const float *d_blocks,
+                                   uint8_t *d_packets, int *d_packet_bytes, bool first_round, hipStream_t fork)
+{
+    const vbm_setup *s = e->hs;
+    hipError_t err;
+    const int *d_count = e->d_counts_ws + 4 * w;
+    if ((err = hipEventRecord(e->ev_fork, fork)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
+    e->last_nsb = 0;
+    const bool has_big = first_round && cap[3] > 0;
+    auto job_of = [&](int m, int part) {
+        type_job j;
+        j.m = m; j.w = w; j.lane0 = lane0[m]; j.bound = cap[m]; j.d_nsb = d_count + m;
+        j.pcm = d_blocks + (size_t)lane0[m] * e->ch * s->blocksizes[1];
+        j.d_packets = d_packets ? d_packets + (size_t)lane0[m] * e->max_packet_bytes : nullptr;
+        j.d_packet_bytes = d_packet_bytes ? d_packet_bytes + lane0[m] : nullptr;
+        j.big = false; j.timed = false; j.depmask = 0;
+        j.part = part; j.grouped = true;
+        return j;
+    };
+    // newest state event of every queue before this round: (workspace, type) of the last job on sub[0..3] and of
+    // the big batch of the call BEFORE this one
+    int last_w[4], prev_big_w = e->prev_call_big_w;
+    for (int t = 0; t < 4; t++) last_w[t] = e->queue_last_w[t];
+    if (first_round) prev_big_w = e->call_big_w;      // (call_big_w still names the previous call's)
+    static const unsigned follows[4] = {0x7u, 0x7u, 0xfu, 0xcu};   // bit t: a block of this type may follow one of type t
+    auto wait_preds = [&](hipStream_t q, int m, int own_queue) -> int {
+        for (int t = 0; t < 4; t++) {
+            if (!((follows[m] >> t) & 1u)) continue;
+            if (t != own_queue && last_w[t] >= 0 &&
+                (err = hipStreamWaitEvent(q, e->ev_state[last_w[t]][t], 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
+            if (t == 3 && own_queue != 4 && prev_big_w >= 0 &&
+                (err = hipStreamWaitEvent(q, e->ev_state_big[prev_big_w], 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
+        }
+        return VBM_OK;
+    };
+    int rc;
+    if (has_big) {      // the long pole first
+        hipStream_t qF = e->sub[4], qB = e->sub[5];
+        if ((err = hipStreamWaitEvent(qF, e->ev_fork, 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
+        if ((rc = wait_preds(qF, 3, 4))) return rc;
+        type_job jf = job_of(3, 1), jb = job_of(3, 2);
+        if ((rc = run_group(e, e->gJ[w][3][1], qF, &jf, 1, 1))) return rc;
+        if ((err = hipEventRecord(e->ev_state_big[w], qF)) != hipSuccess ||
+            (err = hipStreamWaitEvent(qB, e->ev_state_big[w], 0)) != hipSuccess) return vbm_set_hip_error(err, "big batch hand-over");
+        if ((rc = run_group(e, e->gJ[w][3][2], qB, &jb, 1, 2))) return rc;
+        if ((rc = copy_outputs(e, jb, qB))) return rc;
+        if ((err = hipEventRecord(e->ev_done[w][3], qB)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
+        e->done_pending[w][3] = true;
+        e->reuse_pending[w][3] = true;
+        e->slot_queue[w][3] = 4;
+        e->epoch[w][3]++;
+    }
+    for (int m = 0; m < 4; m++) {
+        if (!cap[m] || (m == 3 && has_big)) continue;
+        hipStream_t q = e->sub[m];
+        if ((err = hipStreamWaitEvent(q, e->ev_fork, 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
+        if ((rc = wait_preds(q, m, m))) return rc;
+        type_job j = job_of(m, 0);
+        // (one graph for the whole pipeline: the state event then stands at its end — a small batch is short)
+        if ((rc = run_group(e, e->gJ[w][m][0], q, &j, 1, 0))) return rc;
+        if ((err = hipEventRecord(e->ev_state[w][m], q)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
+        if ((rc = copy_outputs(e, j, q))) return rc;
+        if ((err = hipEventRecord(e->ev_done[w][m], q)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
+        e->done_pending[w][m] = true;
+        e->reuse_pending[w][m] = true;
+        e->slot_queue[w][m] = (signed char)m;
+        e->epoch[w][m]++;
+        e->queue_last_w[m] = w;
+    }
+    if (has_big) {
+        e->prev_call_big_w = e->call_big_w;
+        e->call_big_w = w; e->lazy_w = w; e->lazy_m = 3;
+    }
+    e->round_w = w;
+    e->device_rounds = true;
     return VBM_OK;
 }
 
@@ -1072,6 +1284,23 @@ int vbm_encoder_device_round_run(vbm_encoder *e, int w, const int *lane0, const 
     hipError_t err;
     for (int m = 0; m < 4; m++)
         if (cap[m] < 0 || (lane0[m] & 63) || lane0[m] + cap[m] > e->Ls || (cap[m] && s->modes < 2 && (m >> 1))) return VBM_EINVAL;
+    if (d_count != e->d_counts_ws + 4 * w) return VBM_EINVAL;
+    if (e->use_graphs < 0) {
+        const char *env = getenv("VBM_DEVICE_GRAPHS");     // 0: plain launches, 1 (default): HIP graphs, 2: groups without capture
+        e->use_graphs = env ? atoi(env) : 1;
+    }
+    // Stage timing needs the plain launches (events between the kernels); a managed-bitrate back half writes the
+    // chosen packets straight to the caller's buffers, which change from call to call: plain launches as well.
+    const int mode = (e->use_graphs && !e->profiling && !s->managed) ? 1 : 2;
+    if (e->device_mode && e->device_mode != mode) {
+        // the two ways use different internal streams: everything in flight is waited for at the switch
+        for (int ww = 0; ww < e->nws; ww++)
+            for (int t = 0; t < 4; t++)
+                if (e->reuse_pending[ww][t] && (err = hipStreamWaitEvent(fork, e->ev_done[ww][t], 0)) != hipSuccess)
+                    return vbm_set_hip_error(err, "hipStreamWaitEvent");
+    }
+    e->device_mode = mode;
+    if (mode == 1) return device_round_run_graphs(e, w, lane0, cap, d_blocks, d_packets, d_packet_bytes, first_round, fork);
     if ((err = hipEventRecord(e->ev_fork, fork)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
     e->last_nsb = 0;
     if (first_round) e->call_big_w = -1;

@@ -23,7 +23,8 @@ vbm_setup_host *vbm_setup_handle_host(vbm_setup_handle *h);
 int vbm_encoder_streams(const vbm_encoder *e);
 int vbm_encoder_workspaces(const vbm_encoder *e);
 int vbm_encoder_reset_streams_dev(vbm_encoder *e, const int *d_ids, int n, hipStream_t q);
-int vbm_encoder_device_round_open(vbm_encoder *e, hipStream_t fork, int *w_out, int **d_stream_id, uint8_t **d_wflags, int *lanes);
+int vbm_encoder_device_round_open(vbm_encoder *e, hipStream_t fork, int *w_out, int **d_stream_id, uint8_t **d_wflags, int *lanes,
+                                  int **d_counts);
 int vbm_encoder_device_round_run(vbm_encoder *e, int w, const int *lane0, const int *cap, const int *d_count,
                                  const float *d_blocks, uint8_t *d_packets, int *d_packet_bytes, bool first_round,
                                  hipStream_t fork);
@@ -717,9 +718,9 @@ extern "C" int vbm_frontend_encode_rounds_device(vbm_frontend *fe, int nrounds, 
     if ((err = hipMemsetAsync(fe->d_hold_call, 0, (size_t)S, q)) != hipSuccess) return vbm_set_hip_error(err, "hipMemsetAsync(hold)");
     for (int r = 0; r < nrounds; r++) {
         int w, ws_lanes;
-        int *d_sid;
+        int *d_sid, *counts_ws;
         uint8_t *d_wf;
-        rc = vbm_encoder_device_round_open(fe->enc, q, &w, &d_sid, &d_wf, &ws_lanes);
+        rc = vbm_encoder_device_round_open(fe->enc, q, &w, &d_sid, &d_wf, &ws_lanes, &counts_ws);
         if (rc) return rc;
         if (ws_lanes < fe->lanes) {
             g_vbm_err = "encoder workspace too small for rounds built on the device: create it with max_batch >= vbm_device_round_lanes()";
@@ -731,7 +732,7 @@ extern "C" int vbm_frontend_encode_rounds_device(vbm_frontend *fe, int nrounds, 
         vbm_fe_round R;
         for (int m = 0; m < 4; m++) { R.lane0[m] = fe->lane0[m]; R.cap[m] = fe->lane_cap[m]; }
         R.first_round = r == 0;
-        R.count = counts_r;
+        R.count = counts_ws;        // the workspace's own counts: what the round's kernels (and graphs) read
         R.slot = fe->d_slot;
         R.hold = fe->d_hold_call;
         R.stream_id = d_sid;
@@ -740,14 +741,16 @@ extern "C" int vbm_frontend_encode_rounds_device(vbm_frontend *fe, int nrounds, 
         R.info = d_info + (size_t)r * fe->lanes;
         R.stats = fe->d_stats;
         if (vbm_fe_launch_round_plan(&fe->f, ds, &R, fe->d_type, fe->d_dec, bytes_r, fe->lanes, q)) return VBM_EHIP;
+        if ((err = hipMemcpyAsync(counts_r, counts_ws, 4 * sizeof(int), hipMemcpyDeviceToDevice, q)) != hipSuccess)
+            return vbm_set_hip_error(err, "hipMemcpyAsync(counts)");
         for (int m = 0; m < 4; m++) {
             if (!fe->lane_cap[m]) continue;
             const int N = (m >> 1) ? bs1 : bs0;
             if (vbm_fe_launch_gather(&fe->f, d_sid + fe->lane0[m], fe->d_begin_lane + fe->lane0[m], fe->lane_cap[m], N,
-                                     blocks + (size_t)fe->lane0[m] * ch * bs1, counts_r + m, q))
+                                     blocks + (size_t)fe->lane0[m] * ch * bs1, counts_ws + m, q))
                 return VBM_EHIP;
         }
-        rc = vbm_encoder_device_round_run(fe->enc, w, fe->lane0, fe->lane_cap, counts_r, blocks,
+        rc = vbm_encoder_device_round_run(fe->enc, w, fe->lane0, fe->lane_cap, counts_ws, blocks,
                                           d_packets ? d_packets + (size_t)r * fe->lanes * maxb : nullptr, bytes_r, r == 0, q);
         if (rc) return rc;
         if (vbm_fe_launch_shift(&fe->f, fe->d_dec, q)) return VBM_EHIP;

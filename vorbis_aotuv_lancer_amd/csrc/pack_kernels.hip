@@ -826,10 +826,21 @@ extern "C" int vbm_launch_bitrate_choose(const vbm_batch *b, uint8_t *d_packets,
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// the packet tiles start out as zeros (the bit runs are OR-ed in); a kernel of our own rather than hipMemsetAsync, so
+// that the launch sequence of a round is kernels only (it is replayed as a HIP graph, capi_encoder.cpp)
+static __global__ void k_zero_u128(uint4 *__restrict__ p, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 extern "C" int vbm_launch_pack_head(const vbm_batch *b, hipStream_t st)
 {
     const unsigned tiles = (unsigned)((b->nsb + 63) / 64);
-    if (hipMemsetAsync(b->packetT, 0, (size_t)tiles * 64 * b->max_packet_bytes, st) != hipSuccess) return -2;
+    {
+        const size_t n16 = (size_t)tiles * 64 * b->max_packet_bytes / 16;   // max_packet_bytes is a multiple of 4: 64 * 4 = 256 B per row group
+        hipLaunchKernelGGL(k_zero_u128, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, (uint4 *)b->packetT, n16);
+    }
     hipLaunchKernelGGL(k_pack_head, dim3(tiles), dim3(64), 0, st, *b);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
