@@ -1102,17 +1102,33 @@ int vbm_encoder_device_round_open(vbm_encoder *e, hipStream_t fork, int *w_out, 
         // latency is what the short-block runs of a stream wait for.  (VBM_SMALL_PRIORITY=0: plain streams.)
         e->small_streams_set = true;
         const char *env = getenv("VBM_SMALL_PRIORITY");
-        if (!env || atoi(env)) {
-            int lo = 0, hi = 0;
-            if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo)
-                for (int m = 0; m < 4; m++) {
-                    hipStream_t q;
-                    if (hipStreamCreateWithPriority(&q, hipStreamNonBlocking, hi) == hipSuccess) {
-                        (void)hipStreamSynchronize(e->sub[m]);
-                        (void)hipStreamDestroy(e->sub[m]);
-                        e->sub[m] = q;
-                    }
-                }
+        int lo = 0, hi = 0;
+        const bool have = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo;
+        auto replace = [&](int m, int prio) {
+            hipStream_t q;
+            if (hipStreamCreateWithPriority(&q, hipStreamNonBlocking, prio) == hipSuccess) {
+                (void)hipStreamSynchronize(e->sub[m]);
+                (void)hipStreamDestroy(e->sub[m]);
+                e->sub[m] = q;
+            }
+        };
+        if (have && (!env || atoi(env)))
+            for (int m = 0; m < 4; m++) replace(m, hi);
+        // The big batch's two halves have to sit on different hardware queues to overlap (back half of one call
+        // beside the front half of the next); streams of one priority share a small pool of queues, a stream of
+        // another priority gets one of its own.  VBM_BACK_PRIORITY: -1 high, 1 low, 0 leave it (default low).
+        const char *bp = getenv("VBM_BACK_PRIORITY");
+        const int bprio = bp ? atoi(bp) : 0;
+        if (have && bprio) replace(5, bprio < 0 ? hi : lo);
+        // (measured: a back-half stream of another priority made the step 30x slower; the default leaves it alone)
+        if (const char *bs = getenv("VBM_BACK_STREAM")) {
+            // experiment: which internal stream carries the big batch's back half decides which hardware queue it
+            // shares; "aux" = the tone-branch stream of the per-block path (idle here), "new" = a stream made now
+            if (!strcmp(bs, "aux") && !e->aux.empty()) std::swap(e->sub[5], e->aux[0]);
+            else if (!strcmp(bs, "new")) {
+                hipStream_t q;
+                if (hipStreamCreateWithFlags(&q, hipStreamNonBlocking) == hipSuccess) e->sub[5] = q;   // (the old one stays alive: its queue slot too)
+            }
         }
     }
     const int w = e->next;
