@@ -337,6 +337,9 @@ def main():
             live = nb_last[nb_last >= 0]
             stat["mean_bytes"] = float(live.float().mean().item()) if len(live) else 0.0
             stat["max_buffered_end"] = fe.max_buffered
+            stat["refused_writes"] = fe.refused_writes
+            if fe.refused_writes:
+                raise SystemExit(f"invalid run: {fe.refused_writes} writes were refused (stream buffers full): more rounds per write needed")
         else:
             nb_last = kept[-1][2]
             stat["mean_bytes"] = float(nb_last.float().mean().item()) if len(nb_last) else 0.0

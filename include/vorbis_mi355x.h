@@ -255,9 +255,10 @@ int vbm_frontend_restart_streams(vbm_frontend *fe, const int *stream_ids, int n,
 /* Buffer occupancy, for callers that do not drain completely after every write (a stream inside a
  * run of short blocks yields up to 8 blocks per 1024 samples, each in its own round): the most
  * samples any stream holds now, and the occupancy a write may not exceed (VBM_EINVAL beyond it).  The buffer
- * is 16 long blocks per channel (environment VBM_FE_BUFFER_BLOCKS, 8..64, read at create), 3 of them reserved
- * for the end-of-stream padding: the slack lets such a stream fall behind and catch up, instead of forcing
- * extra rounds on every write.  (The reference grows its buffer on demand: lib/block.c:424-430.) */
+ * is 24 long blocks per channel (environment VBM_FE_BUFFER_BLOCKS, 8..64, read at create): 3 of them reserved
+ * for the end-of-stream padding, a third for the origin of the samples to climb before they are moved back to the
+ * start (one copy per several blocks where the reference memmoves after every block), the rest is slack that lets
+ * such a stream fall behind and catch up, instead of forcing extra rounds on every write.  (The reference grows its buffer on demand: lib/block.c:424-430.) */
 int vbm_frontend_max_buffered(const vbm_frontend *fe);
 int vbm_frontend_capacity(const vbm_frontend *fe);
 int vbm_frontend_encode_round(vbm_frontend *fe, uint8_t *d_packets, int *d_packet_bytes,
@@ -316,8 +317,9 @@ int vbm_frontend_join(vbm_frontend *fe, void *stream);
 int vbm_device_round_lanes(const vbm_setup_handle *setup, int nstreams);
 int vbm_frontend_encode_rounds_device(vbm_frontend *fe, int nrounds, uint8_t *d_packets, int *d_packet_bytes,
                                       vbm_packet_info *d_info, int *d_counts, int lazy, void *stream);
-/* running totals of the device-built rounds: out[0..3] blocks of type 0..3, out[4] samples all streams advanced by
- * (synchronises the front end's stream) */
+/* running totals of the device-built rounds: out[0..3] blocks of type 0..3, out[4] samples all streams advanced by,
+ * out[5] writes the device refused because a stream's buffer was full (must stay 0: the refused samples are lost —
+ * the device-side counterpart of vbm_frontend_write's VBM_EINVAL).  Synchronises the front end's stream. */
 int vbm_frontend_device_stats(vbm_frontend *fe, unsigned long long *out);
 
 /* ---- stream wrapper, host only ------------------------------------------------

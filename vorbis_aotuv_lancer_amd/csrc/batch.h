@@ -36,6 +36,7 @@ struct vbm_batch {
     int ch;
     int nsb;                        // stream-blocks in this batch (with d_nsb set: the most it may hold = launch bound)
     int ncb;                        // channel-blocks = nsb*ch
+    int few;                        // the batch holds few blocks whatever nsb (= the launch bound) says: latency-bound variants
     const int *d_nsb;               // device-resident count of a round built on the device (frontend: k_fe_plan), or NULL:
                                     //   kernels take vbm_nsb(b) / vbm_ncb(b), launchers size their grids for nsb
     int L;                          // ncb rounded up to 64

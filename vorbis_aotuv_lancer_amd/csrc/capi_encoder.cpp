@@ -103,7 +103,7 @@ struct vbm_encoder {
     hipEvent_t ev_state_big[kMaxWS] = {};  // front half of the big batch run in the workspace
     int queue_last_w[4] = {-1, -1, -1, -1};   // workspace of the newest job on sub[0..3]
     int prev_call_big_w = -1;
-    bool small_streams_set = false;
+    bool small_streams_set = false, small_share = false;
     hipEvent_t ev_cap_fork = nullptr, ev_cap_join[4] = {};
     int *d_counts_ws = nullptr;            // [kMaxWS][4] block counts of the round in each workspace
     int use_graphs = -1;
@@ -174,7 +174,9 @@ extern "C" void vbm_encoder_destroy(vbm_encoder *e)
         if (e->ev_cap_join[i]) (void)hipEventDestroy(e->ev_cap_join[i]);
     for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : e->ev_join) (void)hipEventDestroy(ev);
-    for (hipStream_t q : e->sub) (void)hipStreamDestroy(q);
+    if (e->small_share && e->sub.size() >= 4) { e->sub[1] = nullptr; e->sub[3] = nullptr; }   // (aliases of sub[0] / sub[2])
+    for (hipStream_t q : e->sub)
+        if (q) (void)hipStreamDestroy(q);
     for (hipStream_t q : e->aux) (void)hipStreamDestroy(q);
     for (hipEvent_t ev : e->ev_aux_fork) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : e->ev_aux_join) (void)hipEventDestroy(ev);
@@ -812,6 +814,7 @@ struct type_job {
     unsigned depmask;            // bit (ww * 4 + t): slot (ww, t) holds a batch this one's streams may come from
     // rounds run as graphs (device_round_run_graphs): the job is one piece of a group that is forked from / joined
     // to its origin stream by the caller, in or outside a stream capture
+    int few = 0;                 // small batch behind a large launch bound (device-built rounds): latency-bound kernel variants
     int part = 0;                // 0 whole pipeline, 1 front half only (up to the block-state update), 2 back half only
     bool grouped = false;        // no ev_fork wait, no dependency waits, no state / done events, no output copy
     hipStream_t q_on = nullptr;  // grouped: the stream to enqueue on
@@ -831,6 +834,7 @@ static int enqueue_job(vbm_encoder *e, const type_job &j)
     vbm_batch v = slice_of(full, j.lane0, j.bound);
     v.pcm = j.pcm;
     v.d_nsb = j.d_nsb;
+    v.few = j.few;
     const int W = v.W;
     const bool pr = j.timed;
 #define RUN(x) do { rc = (x); if (rc) { g_vbm_err = std::string("launch failed: ") + #x; return VBM_EHIP; } } while (0)
@@ -1088,47 +1092,47 @@ int vbm_encoder_device_round_open(vbm_encoder *e, hipStream_t fork, int *w_out, 
 {
     int rc = vbm_encoder_set_sub_batches(e, e->nsplit);
     if (rc) return rc;
-    while ((int)e->sub.size() < 6) {
-        hipStream_t q;
-        hipEvent_t ev;
-        if (hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return VBM_EHIP;
-        e->sub.push_back(q);
-        e->ev_join.push_back(ev);
-    }
     if (!e->small_streams_set) {
-        // The small batches are chains of ~40 short kernels; beside the big batch every one of them queues behind
-        // its wide launches.  On high-priority streams their workgroups go first (they are few): the chain's
-        // latency is what the short-block runs of a stream wait for.  (VBM_SMALL_PRIORITY=0: plain streams.)
+        // Streams of the device-built rounds.  sub[0..3]: the small batches, chains of ~40 short kernels; beside the
+        // big batch every one of them queues behind its wide launches, so they get high priority (their workgroups
+        // are few and go first: the chain's latency is what the short-block runs of a stream wait for;
+        // VBM_SMALL_PRIORITY=0: plain streams).  sub[4], sub[5]: front and back half of the big batch.  The runtime
+        // hands out a limited number of hardware queues per priority (GPU_MAX_HW_QUEUES) in the order the streams
+        // are made and lets later streams share: the two big-batch streams are made before the others, so that
+        // they do not end up on one queue (the back half of a call has to run beside the front half of the next).
         e->small_streams_set = true;
         const char *env = getenv("VBM_SMALL_PRIORITY");
         int lo = 0, hi = 0;
-        const bool have = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo;
-        auto replace = [&](int m, int prio) {
+        const bool prio = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo && (!env || atoi(env));
+        while ((int)e->sub.size() < 6) {
+            e->sub.push_back(nullptr);
+            hipEvent_t ev;
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return VBM_EHIP;
+            e->ev_join.push_back(ev);
+        }
+        // VBM_SMALL_STREAMS=2: types 0 / 1 share one stream, types 2 / 3 another (fewer hardware queues in play)
+        const char *ss = getenv("VBM_SMALL_STREAMS");
+        e->small_share = ss && atoi(ss) == 2;
+        static const int order[6] = {4, 5, 0, 1, 2, 3};
+        for (int k = 0; k < 6; k++) {
+            const int m = order[k];
+            const bool want_prio = prio && m < 4;
+            if (e->sub[m] && !want_prio) continue;
             hipStream_t q;
-            if (hipStreamCreateWithPriority(&q, hipStreamNonBlocking, prio) == hipSuccess) {
+            hipError_t cerr = want_prio ? hipStreamCreateWithPriority(&q, hipStreamNonBlocking, hi)
+                                        : hipStreamCreateWithFlags(&q, hipStreamNonBlocking);
+            if (cerr != hipSuccess) return vbm_set_hip_error(cerr, "hipStreamCreate");
+            if (e->sub[m]) {
                 (void)hipStreamSynchronize(e->sub[m]);
                 (void)hipStreamDestroy(e->sub[m]);
-                e->sub[m] = q;
             }
-        };
-        if (have && (!env || atoi(env)))
-            for (int m = 0; m < 4; m++) replace(m, hi);
-        // The big batch's two halves have to sit on different hardware queues to overlap (back half of one call
-        // beside the front half of the next); streams of one priority share a small pool of queues, a stream of
-        // another priority gets one of its own.  VBM_BACK_PRIORITY: -1 high, 1 low, 0 leave it (default low).
-        const char *bp = getenv("VBM_BACK_PRIORITY");
-        const int bprio = bp ? atoi(bp) : 0;
-        if (have && bprio) replace(5, bprio < 0 ? hi : lo);
-        // (measured: a back-half stream of another priority made the step 30x slower; the default leaves it alone)
-        if (const char *bs = getenv("VBM_BACK_STREAM")) {
-            // experiment: which internal stream carries the big batch's back half decides which hardware queue it
-            // shares; "aux" = the tone-branch stream of the per-block path (idle here), "new" = a stream made now
-            if (!strcmp(bs, "aux") && !e->aux.empty()) std::swap(e->sub[5], e->aux[0]);
-            else if (!strcmp(bs, "new")) {
-                hipStream_t q;
-                if (hipStreamCreateWithFlags(&q, hipStreamNonBlocking) == hipSuccess) e->sub[5] = q;   // (the old one stays alive: its queue slot too)
-            }
+            e->sub[m] = q;
+        }
+        if (e->small_share) {
+            (void)hipStreamDestroy(e->sub[1]);
+            (void)hipStreamDestroy(e->sub[3]);
+            e->sub[1] = e->sub[0];
+            e->sub[3] = e->sub[2];
         }
     }
     const int w = e->next;
@@ -1271,11 +1275,15 @@ static int device_round_run_graphs(vbm_encoder *e, int w, const int *lane0, cons
         hipStream_t q = e->sub[m];
         if ((err = hipStreamWaitEvent(q, e->ev_fork, 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
         if ((rc = wait_preds(q, m, m))) return rc;
-        type_job j = job_of(m, 0);
-        // (one graph for the whole pipeline: the state event then stands at its end — a small batch is short)
-        if ((rc = run_group(e, e->gJ[w][m][0], q, &j, 1, 0))) return rc;
+        // two graphs, the state event between them: what follows this batch on another stream waits for its front
+        // half only (the chain short blocks -> transition -> long blocks of the next call is what the big batch of
+        // the next call waits for)
+        type_job j = job_of(m, 1), j2 = job_of(m, 2);
+        j.few = j2.few = 1;
+        if ((rc = run_group(e, e->gJ[w][m][1], q, &j, 1, 0))) return rc;
         if ((err = hipEventRecord(e->ev_state[w][m], q)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
-        if ((rc = copy_outputs(e, j, q))) return rc;
+        if ((rc = run_group(e, e->gJ[w][m][2], q, &j2, 1, 0))) return rc;
+        if ((rc = copy_outputs(e, j2, q))) return rc;
         if ((err = hipEventRecord(e->ev_done[w][m], q)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
         e->done_pending[w][m] = true;
         e->reuse_pending[w][m] = true;

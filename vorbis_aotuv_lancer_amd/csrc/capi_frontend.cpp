@@ -95,6 +95,9 @@ extern "C" void vbm_frontend_destroy(vbm_frontend *fe)
 static int fe_enter(vbm_frontend *fe, void *stream)
 {
     hipError_t err;
+    static int skip = -1;
+    if (skip < 0) skip = getenv("VBM_DEBUG_NO_ENTER") ? 1 : 0;   // timing experiments only
+    if (skip) return VBM_OK;
     if ((err = hipEventRecord(fe->ev_in, (hipStream_t)stream)) != hipSuccess ||
         (err = hipStreamWaitEvent(fe->q, fe->ev_in, 0)) != hipSuccess) return vbm_set_hip_error(err, "front end stream hand-over");
     return VBM_OK;
@@ -130,11 +133,12 @@ extern "C" int vbm_frontend_create(vbm_frontend **out, vbm_encoder *enc)
     // what is left is slack: a stream inside a run of short blocks falls behind the others and catches up
     // later, and the more it may fall behind, the fewer rounds a write forces (VBM_FE_BUFFER_BLOCKS, 8..64;
     // measured at 16384 streams, one 1024-sample write per step: 8 -> 11.9 ms, 12 -> 10.1, 16 -> 9.5, 24 -> 9.5).
-    int cap_blocks = 16;
+    int cap_blocks = 24;
     if (const char *env = getenv("VBM_FE_BUFFER_BLOCKS")) cap_blocks = atoi(env);
     if (cap_blocks < 8) cap_blocks = 8;
     if (cap_blocks > 64) cap_blocks = 64;
     f.cap = (long)bs1 * cap_blocks;
+    f.base_max = (int)(bs1 * (cap_blocks / 3));   // a third of the buffer: the origin climbs this far before a compaction
     f.plane = (long)S * ch * f.cap;
     f.marks = (int)(f.cap / 64) + 8;
     int rc = 0;
@@ -142,6 +146,8 @@ extern "C" int vbm_frontend_create(vbm_frontend **out, vbm_encoder *enc)
     const size_t SC = (size_t)S * ch;
     A(f.pcm, float, (size_t)2 * f.plane);
     A(f.parity, int, S);
+    A(f.base, int, S);
+    A(f.overflow, int, 1);
     A(f.pcm_current, int, S); A(f.centerW, int, S); A(f.lW, int, S); A(f.W, int, S); A(f.nW, int, S);
     A(f.eofflag, int, S); A(f.preextrapolate, int, S);
     A(f.granulepos, long long, S); A(f.sequence, long long, S);
@@ -202,6 +208,8 @@ extern "C" int vbm_frontend_reset(vbm_frontend *fe)
     auto zero = [&](void *p, size_t bytes) { if (err == hipSuccess) err = hipMemset(p, 0, bytes); };
     zero(f.pcm, (size_t)2 * f.plane * sizeof(float));
     zero(f.parity, S * sizeof(int));
+    zero(f.base, S * sizeof(int));
+    zero(f.overflow, sizeof(int));
     zero(f.lW, S * sizeof(int)); zero(f.W, S * sizeof(int)); zero(f.nW, S * sizeof(int));
     zero(f.eofflag, S * sizeof(int)); zero(f.preextrapolate, S * sizeof(int));
     zero(f.granulepos, S * sizeof(long long));
@@ -248,7 +256,7 @@ extern "C" int vbm_frontend_max_buffered(const vbm_frontend *fe)
 
 extern "C" int vbm_frontend_capacity(const vbm_frontend *fe)
 {
-    return fe ? (int)(fe->f.cap - 3 * fe->hs->blocksizes[1]) : VBM_EINVAL;
+    return fe ? (int)(fe->f.cap - 3 * fe->hs->blocksizes[1] - fe->f.base_max) : VBM_EINVAL;
 }
 
 extern "C" int vbm_frontend_write(vbm_frontend *fe, const float *d_pcm, int vals, void *stream)
@@ -258,7 +266,7 @@ extern "C" int vbm_frontend_write(vbm_frontend *fe, const float *d_pcm, int vals
     const int bs1 = s->blocksizes[1];
     for (int i = 0; i < fe->S; i++) {
         if (fe->ended[i]) { g_vbm_err = "vbm_frontend_write after vbm_frontend_finish"; return VBM_EINVAL; }
-        if (!fe->mirrors_stale && fe->pcm_current[i] + vals > fe->f.cap - 3 * bs1) {   // OV_EINVAL of lib/block.c:540-541
+        if (!fe->mirrors_stale && fe->pcm_current[i] + vals > fe->f.cap - 3 * bs1 - fe->f.base_max) {   // OV_EINVAL of lib/block.c:540-541
             g_vbm_err = "PCM buffer full: drain blocks with vbm_frontend_encode_round before writing more";
             return VBM_EINVAL;
         }
@@ -312,7 +320,7 @@ extern "C" int vbm_frontend_write_streams(vbm_frontend *fe, const int *stream_id
         if (i < 0 || i >= fe->S || seen[i]) return VBM_EINVAL;   // a stream once per call
         seen[i] = 1;
         if (fe->ended[i]) { g_vbm_err = "vbm_frontend_write_streams after vbm_frontend_finish"; return VBM_EINVAL; }
-        if (!fe->mirrors_stale && fe->pcm_current[i] + vals > fe->f.cap - 3 * bs1) {
+        if (!fe->mirrors_stale && fe->pcm_current[i] + vals > fe->f.cap - 3 * bs1 - fe->f.base_max) {
             g_vbm_err = "PCM buffer full: drain blocks with vbm_frontend_encode_round before writing more";
             return VBM_EINVAL;
         }
@@ -449,7 +457,7 @@ static int round_impl(vbm_frontend *fe, uint8_t *d_packets, int *d_packet_bytes,
         if (vbm_fe_launch_ve_range(&fe->f, st)) return VBM_EHIP;
         vbm_ve_gather g;
         g.pcm = fe->f.pcm;
-        g.first = fe->f.ve_first; g.last = fe->f.ve_last; g.parity = fe->f.parity;
+        g.first = fe->f.ve_first; g.last = fe->f.ve_last; g.parity = fe->f.parity; g.base = fe->f.base;
         g.ch = ch; g.steps = VBM_FE_CHUNK; g.cap = fe->f.cap; g.plane = fe->f.plane;
         for (int t0 = 0; t0 < fe->pending_steps; t0 += VBM_FE_CHUNK) {
             g.t0 = t0;
@@ -703,7 +711,7 @@ extern "C" int vbm_frontend_encode_rounds_device(vbm_frontend *fe, int nrounds, 
         if (vbm_fe_launch_ve_range(&fe->f, q)) return VBM_EHIP;
         vbm_ve_gather g;
         g.pcm = fe->f.pcm;
-        g.first = fe->f.ve_first; g.last = fe->f.ve_last; g.parity = fe->f.parity;
+        g.first = fe->f.ve_first; g.last = fe->f.ve_last; g.parity = fe->f.parity; g.base = fe->f.base;
         g.ch = ch; g.steps = VBM_FE_CHUNK; g.cap = fe->f.cap; g.plane = fe->f.plane;
         for (int t0 = 0; t0 < fe->pending_steps; t0 += VBM_FE_CHUNK) {
             g.t0 = t0;
@@ -756,6 +764,7 @@ extern "C" int vbm_frontend_encode_rounds_device(vbm_frontend *fe, int nrounds, 
         if (vbm_fe_launch_shift(&fe->f, fe->d_dec, q)) return VBM_EHIP;
     }
     fe->mirrors_stale = true;
+    if (getenv("VBM_DEBUG_NO_JOIN")) return VBM_OK;   // timing experiments only: outputs are not tied to `stream`
     return lazy ? vbm_analysis_round_join_lazy(fe->enc, stream) : vbm_analysis_round_join(fe->enc, stream);
 }
 
@@ -763,11 +772,15 @@ extern "C" int vbm_frontend_encode_rounds_device(vbm_frontend *fe, int nrounds, 
 extern "C" int vbm_frontend_device_stats(vbm_frontend *fe, unsigned long long *out)
 {
     if (!fe || !out) return VBM_EINVAL;
-    for (int i = 0; i < 5; i++) out[i] = 0;
-    if (!fe->d_stats) return VBM_OK;
+    for (int i = 0; i < 6; i++) out[i] = 0;
     hipError_t err;
+    int ov = 0;
     if ((err = hipStreamSynchronize(fe->q)) != hipSuccess ||
-        (err = hipMemcpy(out, fe->d_stats, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost)) != hipSuccess)
+        (err = hipMemcpy(&ov, fe->f.overflow, sizeof(int), hipMemcpyDeviceToHost)) != hipSuccess)
+        return vbm_set_hip_error(err, "hipMemcpy(stats)");
+    out[5] = (unsigned long long)ov;
+    if (!fe->d_stats) return VBM_OK;
+    if ((err = hipMemcpy(out, fe->d_stats, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost)) != hipSuccess)
         return vbm_set_hip_error(err, "hipMemcpy(stats)");
     return VBM_OK;
 }

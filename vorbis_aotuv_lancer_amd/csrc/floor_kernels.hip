@@ -630,7 +630,7 @@ extern "C" int vbm_launch_floor_fit(const vbm_batch *b, hipStream_t st)
                                   80 * 1024);
         allowed = true;
     }
-    if (lds <= 80 * 1024 && lpw == 64 && (force || b->ncb <= 64 * 64) && !getenv("VBM_FLOORFIT_PRIVATE"))
+    if (lds <= 80 * 1024 && lpw == 64 && (force || b->few || b->ncb <= 64 * 64) && !getenv("VBM_FLOORFIT_PRIVATE"))
         hipLaunchKernelGGL(k_floor_fit<true>, dim3((unsigned)((b->ncb + 63) / 64)), dim3(64), lds, st, *b, 64);
     else
         hipLaunchKernelGGL(k_floor_fit<false>, dim3((unsigned)((b->ncb + lpw - 1) / lpw)), dim3(64), 0, st, *b, lpw);
@@ -645,7 +645,7 @@ extern "C" int vbm_launch_floor_encode(const vbm_batch *b, hipStream_t st)
 {
     hipLaunchKernelGGL(k_floor_encode, grid_for(b->ncb), dim3(64), 0, st, *b);
     int nchunks = b->n >= 1024 ? 8 : b->n >= 256 ? 4 : 2;
-    if (b->ncb <= 1024 && b->n / 16 > nchunks) nchunks = b->n / 16;   // small batch: latency-bound, finer slices
+    if ((b->few || b->ncb <= 1024) && b->n / 16 > nchunks) nchunks = b->n / 16;   // small batch: latency-bound, finer slices
     hipLaunchKernelGGL(k_floor_render, dim3((unsigned)((b->ncb + 63) / 64), (unsigned)nchunks), dim3(64), 0, st, *b, nchunks);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

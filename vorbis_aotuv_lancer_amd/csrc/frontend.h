@@ -5,8 +5,9 @@
 // Every stream keeps the reference's own coordinates (centerW, pcm_current, ve_current, ... are the
 // same numbers the reference would hold), so the decisions can be checked value by value.  The
 // PCM of a channel lives in one of two buffers of `cap` floats; where the reference memmove()s the
-// buffer down after a block (lib/block.c:757-759), the shift kernel copies into the other buffer
-// and flips the stream's parity.
+// buffer down after a block (lib/block.c:757-759), the stream's origin `base` inside the buffer moves up
+// instead, and only when it has passed base_max does the shift kernel copy the live samples to the start of
+// the other buffer and flip the stream's parity (one copy per several blocks instead of one per block).
 #pragma once
 #include <stdint.h>
 #include "setup.h"
@@ -21,6 +22,9 @@ struct vbm_fe_state {
     int marks;                   // entries of the per-stream mark ring (cap/64 + 8)
     float *pcm;                  // [2][S*ch][cap]
     int *parity;                 // [S]
+    int *base;                   // [S] where the stream's sample 0 sits in its channel buffers (see k_fe_shift)
+    int base_max;                // the buffers are compacted once base would pass this
+    int *overflow;               // [1] writes refused because a stream's buffer was full (device-built rounds: no host check)
     // vorbis_dsp_state (lib/block.c:173-344 initial values)
     int *pcm_current, *centerW, *lW, *W, *nW, *eofflag, *preextrapolate;   // [S]
     long long *granulepos, *sequence;                                      // [S]

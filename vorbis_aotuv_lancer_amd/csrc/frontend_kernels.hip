@@ -29,7 +29,7 @@ namespace {
 
 __device__ __forceinline__ float *chan_buf(const vbm_fe_state &f, int s, int c)
 {
-    return f.pcm + (long)f.parity[s] * f.plane + ((long)s * f.ch + c) * f.cap;
+    return f.pcm + (long)f.parity[s] * f.plane + ((long)s * f.ch + c) * f.cap + f.base[s];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -37,7 +37,8 @@ __global__ void k_fe_append(vbm_fe_state f, const float *__restrict__ src, int v
 {
     const int c = blockIdx.x;                       // channel index over S*ch
     const int s = c / f.ch;
-    float *dst = f.pcm + (long)f.parity[s] * f.plane + (long)c * f.cap + f.pcm_current[s];
+    if (f.base[s] + f.pcm_current[s] + vals > f.cap) return;   // full (k_fe_commit counts it): never write past the buffer
+    float *dst = f.pcm + (long)f.parity[s] * f.plane + (long)c * f.cap + f.base[s] + f.pcm_current[s];
     const float *in = src + (long)c * vals;
     for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < vals; i += gridDim.y * blockDim.x)
         dst[i] = in[i] * pre_amplitude;             // lib/block.c:514-518
@@ -46,7 +47,9 @@ __global__ void k_fe_append(vbm_fe_state f, const float *__restrict__ src, int v
 __global__ void k_fe_commit(vbm_fe_state f, int vals)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < f.S) f.pcm_current[s] += vals;
+    if (s >= f.S) return;
+    if (f.base[s] + f.pcm_current[s] + vals > f.cap) { atomicAdd(f.overflow, 1); return; }
+    f.pcm_current[s] += vals;
 }
 
 // the same for a subset of the streams: src holds [k][ch][vals] for stream ids[k]
@@ -56,7 +59,8 @@ __global__ void k_fe_append_ids(vbm_fe_state f, const int *__restrict__ ids, con
     const int kc = blockIdx.x;                      // listed stream k, channel c
     const int k = kc / f.ch, c = kc % f.ch;
     const int s = ids[k];
-    float *dst = f.pcm + (long)f.parity[s] * f.plane + ((long)s * f.ch + c) * f.cap + f.pcm_current[s];
+    if (f.base[s] + f.pcm_current[s] + vals > f.cap) return;
+    float *dst = f.pcm + (long)f.parity[s] * f.plane + ((long)s * f.ch + c) * f.cap + f.base[s] + f.pcm_current[s];
     const float *in = src + (long)kc * vals;
     for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < vals; i += gridDim.y * blockDim.x)
         dst[i] = in[i] * pre_amplitude;
@@ -65,7 +69,10 @@ __global__ void k_fe_append_ids(vbm_fe_state f, const int *__restrict__ ids, con
 __global__ void k_fe_commit_ids(vbm_fe_state f, const int *__restrict__ ids, int n, int vals)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n) f.pcm_current[ids[k]] += vals;
+    if (k >= n) return;
+    const int s = ids[k];
+    if (f.base[s] + f.pcm_current[s] + vals > f.cap) { atomicAdd(f.overflow, 1); return; }
+    f.pcm_current[s] += vals;
 }
 
 // vorbis_analysis_init state for the listed streams (a new stream starts in a used slot): lib/block.c:306-344,
@@ -78,7 +85,7 @@ __global__ void k_fe_restart(vbm_fe_state f, const int *__restrict__ ids, int n,
     const int s = ids[lane / f.ch], ci = lane % f.ch;
     const long SC = (long)f.S * f.ch, c = (long)s * f.ch + ci;
     // the reference's buffer starts zeroed: the first centerW samples are silence until they are extrapolated
-    float *pcm = f.pcm + (long)f.parity[s] * f.plane + c * f.cap;
+    float *pcm = f.pcm + (long)f.parity[s] * f.plane + c * f.cap;   // (the new stream starts at the buffer's start)
     for (int i = 0; i < long_n / 2; i++) pcm[i] = 0.f;
     for (int k = 0; k < VBM_VE_AMP; k++)
         for (int jb = 0; jb < 16; jb++) f.ve_ampbuf[((long)k * SC + c) * 16 + jb] = 0.f;
@@ -88,6 +95,7 @@ __global__ void k_fe_restart(vbm_fe_state f, const int *__restrict__ ids, int n,
     f.ve_nearacc[SC + c] = 0.f;
     f.ve_nearptr[c] = 0;
     if (ci == 0) {
+        f.base[s] = 0;
         f.pcm_current[s] = long_n / 2; f.centerW[s] = long_n / 2;
         f.lW[s] = 0; f.W[s] = 0; f.nW[s] = 0; f.eofflag[s] = 0; f.preextrapolate[s] = 0;
         f.granulepos[s] = 0; f.sequence[s] = 3;
@@ -683,17 +691,20 @@ __global__ void k_fe_gather(vbm_fe_state f, const int *__restrict__ ids, const i
     for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < N / 4; i += gridDim.y * blockDim.x) out[i] = src[i];
 }
 
-// every stream whose decision of this round moved the buffer: copy the surviving samples into the
-// other buffer; k_fe_flip then switches the parity
+// every stream whose decision of this round moved its window on: the origin moves up by the same amount; once it
+// has passed base_max, the surviving samples are copied to the start of the other buffer (k_fe_flip then switches
+// the parity and resets the origin)
 __global__ void k_fe_shift(vbm_fe_state f, const vbm_fe_decision *__restrict__ dec)
 {
     const int c = blockIdx.x;
     const int s = c / f.ch;
     const int mv = dec[s].movement;
     if (mv <= 0) return;
+    const int nb = f.base[s] + mv;
+    if (nb <= f.base_max) return;
     const int n = f.pcm_current[s];                 // already reduced by the decision
     const int par = f.parity[s];
-    const float4 *src = reinterpret_cast<const float4 *>(f.pcm + (long)par * f.plane + (long)c * f.cap + mv);
+    const float4 *src = reinterpret_cast<const float4 *>(f.pcm + (long)par * f.plane + (long)c * f.cap + nb);
     float4 *dst = reinterpret_cast<float4 *>(f.pcm + (long)(par ^ 1) * f.plane + (long)c * f.cap);
     for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < (n + 3) / 4; i += gridDim.y * blockDim.x) dst[i] = src[i];
 }
@@ -701,7 +712,16 @@ __global__ void k_fe_shift(vbm_fe_state f, const vbm_fe_decision *__restrict__ d
 __global__ void k_fe_flip(vbm_fe_state f, const vbm_fe_decision *__restrict__ dec)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < f.S && dec[s].movement > 0) f.parity[s] ^= 1;
+    if (s >= f.S) return;
+    const int mv = dec[s].movement;
+    if (mv <= 0) return;
+    const int nb = f.base[s] + mv;
+    if (nb > f.base_max) {
+        f.parity[s] ^= 1;
+        f.base[s] = 0;
+    } else {
+        f.base[s] = nb;
+    }
 }
 
 }  // namespace

@@ -9,6 +9,7 @@
 struct vbm_ve_gather {
     const float *pcm;       // buffer 0 of channel 0
     const int *first, *last, *parity;   // [S]
+    const int *base;                    // [S] origin of the stream's samples inside its channel buffers
     int ch, steps, t0;
     long cap, plane;        // floats per channel buffer, floats per buffer set (all channels)
 };

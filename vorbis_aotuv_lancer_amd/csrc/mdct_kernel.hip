@@ -141,7 +141,7 @@ __device__ __forceinline__ const float *block_src(const float *__restrict__ pcm,
     const int s = (int)(c / g.ch);
     const int j = g.first[s] + g.t0 + t;
     if (j >= g.last[s]) return nullptr;
-    return pcm + (long)g.parity[s] * g.plane + c * g.cap + (long)j * 64;
+    return pcm + (long)g.parity[s] * g.plane + c * g.cap + g.base[s] + (long)j * 64;
 }
 
 // group of eight 16-B loads -> registers

@@ -992,7 +992,7 @@ static inline int bin_chunks(const vbm_batch *b)
     const int chunks = b->n >= 1024 ? big : b->n >= 512 ? 8 : b->n >= 256 ? 4 : 2;
     // A small batch (the short rounds of the front end: a few wavefronts on an empty chip) is bound by the
     // latency of each wavefront's walk over its bins, not by throughput: slices of 8-16 bins instead of 64.
-    if (b->ncb <= 1024) {
+    if (b->few || b->ncb <= 1024) {
         int fine = b->n / (b->n >= 1024 ? 16 : 8);
         if (fine > 64) fine = 64;
         if (fine > chunks) return fine;

@@ -297,8 +297,9 @@ class FrontEnd:
 
     def device_stats(self):
         """running totals of the device-built rounds: ([blocks of type 0..3], samples all streams advanced by)"""
-        out = (C.c_ulonglong * 5)()
+        out = (C.c_ulonglong * 6)()
         check(lib.vbm_frontend_device_stats(self._h, out), "vbm_frontend_device_stats")
+        self.refused_writes = int(out[5])      # must stay 0 (a stream's buffer was full: samples lost)
         return [int(out[k]) for k in range(4)], int(out[4])
 
     def close(self):
