@@ -271,14 +271,22 @@ def main():
         counting = [False]
 
         DEVICE_ROUNDS = os.environ.get("VBM_BENCH_DEVICE_ROUNDS", "1") != "0"
-        NROUNDS = int(os.environ.get("VBM_BENCH_ROUNDS", "2"))
+        # rounds per write, cycled: a stream needs ~1.2 blocks per 1024 samples at this signal's block-switching rate
+        # (55 long + 10 short + 2 transition blocks per 57 writes), a stream inside a burst eight; streams that fell
+        # behind catch up one extra block per round.  "2,1" (1.5 per write) keeps every stream's buffer bounded over
+        # hundreds of writes (encoded / input -> 1, max_buffered_samples_at_end steady); "2,1,1,1" and "1" do not.
+        # The warm-up runs three per write to clear the start of the streams, where all deliver short blocks at once.
+        PATTERN = [int(x) for x in os.environ.get("VBM_BENCH_ROUNDS", "2,1").split(",")]
 
         def step_pcm(k):
             fe.write(chunks[k])
             if DEVICE_ROUNDS:
                 # rounds built on the device: the call only enqueues (no decision ever comes back to the host)
-                kept.append(fe.encode_rounds_device(nrounds=NROUNDS, lazy=LAZY_JOIN, device=dev))
-                del kept[:-3]
+                nr = 3 if k < args.warmup else PATTERN[k % len(PATTERN)]
+                if counting[0]:
+                    stat["rounds"] += nr
+                kept.append(fe.encode_rounds_device(nrounds=nr, lazy=LAZY_JOIN, device=dev))
+                del kept[:-6]
                 return
             info, pk_, nb_, counts = fe.encode_rounds(min_rounds=MIN_ROUNDS, max_rounds=16, headroom=HOP, device=dev,
                                                       lazy=LAZY_JOIN)
@@ -332,7 +340,6 @@ def main():
             stat["modes"] = np.array([a - b for a, b in zip(modes1, modes0)], np.int64)
             stat["blocks"] = int(stat["modes"].sum())
             stat["samples"] = samples1 - samples0
-            stat["rounds"] = NROUNDS * args.steps
             nb_last = kept[-1][2]
             live = nb_last[nb_last >= 0]
             stat["mean_bytes"] = float(live.float().mean().item()) if len(live) else 0.0
@@ -444,6 +451,7 @@ def main():
             st = results["pcm"]["stat"]
             line["config"].update({
                 "blocks_encoded": st["blocks"], "rounds": st["rounds"], "rounds_per_write": st["rounds"] / args.steps,
+                "rounds_pattern": os.environ.get("VBM_BENCH_ROUNDS", "2,1"),
                 "blocks_by_mode": {"impulse_short": int(st["modes"][0]), "padding_short": int(st["modes"][1]),
                                    "transition_long": int(st["modes"][2]), "long": int(st["modes"][3])},
                 "short_block_fraction": float(st["modes"][:2].sum() / max(st["blocks"], 1)),

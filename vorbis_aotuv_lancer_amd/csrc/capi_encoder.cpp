@@ -102,7 +102,6 @@ struct vbm_encoder {
     round_graph gJ[kMaxWS][4][3];          // [workspace][block type][0 whole pipeline, 1 front half, 2 back half]
     hipEvent_t ev_state_big[kMaxWS] = {};  // front half of the big batch run in the workspace
     int queue_last_w[4] = {-1, -1, -1, -1};   // workspace of the newest job on sub[0..3]
-    int prev_call_big_w = -1;
     bool small_streams_set = false, small_share = false;
     hipEvent_t ev_cap_fork = nullptr, ev_cap_join[4] = {};
     int *d_counts_ws = nullptr;            // [kMaxWS][4] block counts of the round in each workspace
@@ -1084,9 +1083,8 @@ static int analysis_round_impl(vbm_encoder *e, const int *counts, const int *str
 // ---- rounds built on the device (capi_frontend.cpp: vbm_frontend_encode_rounds_device) ------------------------------
 // The host knows neither which streams deliver a block nor how many: block type m owns the fixed lane region
 // [lane0[m], lane0[m] + cap[m]) of workspace w, its kernels are launched for cap[m] blocks and read the count from
-// d_count[m].  Order of a stream's blocks: the front end holds the streams of a call's first type-3 batch (the big
-// one) for the rest of the call, so a later round of the same call never holds a stream of it; every other batch
-// begun earlier may, and is waited for (its state event; a finished batch costs nothing).
+// d_count[m].  Order of a stream's blocks: every batch begun earlier may hold the block before one of this round's
+// and is waited for (its state event; a finished batch costs nothing) wherever the block types allow the succession.
 int vbm_encoder_device_round_open(vbm_encoder *e, hipStream_t fork, int *w_out, int **d_stream_id, uint8_t **d_wflags, int *lanes,
                                   int **d_counts)
 {
@@ -1216,8 +1214,8 @@ static int run_group(vbm_encoder *e, vbm_encoder::round_graph &g, hipStream_t or
 // short blocks are 0 / 1): a stream's consecutive blocks go 3->3, 3->2, 2->3, 2->2, 2->0/1, 0/1->0/1, 0/1->2, so
 // types 0 / 1 never follow type 3 directly and type 3 never follows them: short batches and long batches only meet
 // through the transition batches.  A job waits for the newest state event of every type it may follow, as they stood
-// before the round's own jobs went in — and, since the front end holds the streams of a call's big batch for the rest
-// of the call, never for the big batch of its own call.
+// before the round's own jobs went in; for the long types that includes the front half of the newest big batch (the
+// call's own in its later rounds: a stream that has fallen behind delivers a long block in every round).
 static int device_round_run_graphs(vbm_encoder *e, int w, const int *lane0, const int *cap, const float *d_blocks,
                                    uint8_t *d_packets, int *d_packet_bytes, bool first_round, hipStream_t fork)
 {
@@ -1238,10 +1236,10 @@ static int device_round_run_graphs(vbm_encoder *e, int w, const int *lane0, cons
         return j;
     };
     // newest state event of every queue before this round: (workspace, type) of the last job on sub[0..3] and of
-    // the big batch of the call BEFORE this one
-    int last_w[4], prev_big_w = e->prev_call_big_w;
+    // the newest big batch (first round: the previous call's; later rounds: this call's)
+    int last_w[4];
+    const int prev_big_w = e->call_big_w;
     for (int t = 0; t < 4; t++) last_w[t] = e->queue_last_w[t];
-    if (first_round) prev_big_w = e->call_big_w;      // (call_big_w still names the previous call's)
     static const unsigned follows[4] = {0x7u, 0x7u, 0xfu, 0xcu};   // bit t: a block of this type may follow one of type t
     auto wait_preds = [&](hipStream_t q, int m, int own_queue) -> int {
         for (int t = 0; t < 4; t++) {
@@ -1291,10 +1289,7 @@ static int device_round_run_graphs(vbm_encoder *e, int w, const int *lane0, cons
         e->epoch[w][m]++;
         e->queue_last_w[m] = w;
     }
-    if (has_big) {
-        e->prev_call_big_w = e->call_big_w;
-        e->call_big_w = w; e->lazy_w = w; e->lazy_m = 3;
-    }
+    if (has_big) { e->call_big_w = w; e->lazy_w = w; e->lazy_m = 3; }
     e->round_w = w;
     e->device_rounds = true;
     return VBM_OK;
@@ -1327,12 +1322,11 @@ int vbm_encoder_device_round_run(vbm_encoder *e, int w, const int *lane0, const 
     if (mode == 1) return device_round_run_graphs(e, w, lane0, cap, d_blocks, d_packets, d_packet_bytes, first_round, fork);
     if ((err = hipEventRecord(e->ev_fork, fork)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
     e->last_nsb = 0;
-    if (first_round) e->call_big_w = -1;
-    // every slot that may still be running, except this round's own and the big batch of this call
+    // every slot that may still be running, except this round's own
     unsigned depmask = 0;
     for (int ww = 0; ww < e->nws; ww++)
         for (int t = 0; t < 4; t++)
-            if (ww != w && e->reuse_pending[ww][t] && !(ww == e->call_big_w && t == 3)) depmask |= 1u << (ww * 4 + t);
+            if (ww != w && e->reuse_pending[ww][t]) depmask |= 1u << (ww * 4 + t);
     const bool prof = e->profiling && e->prof_calls < e->prof_max_calls && e->events_used + 2 * (size_t)kNumStages <= e->events.size();
     int dev_id = 0;
     (void)hipGetDevice(&dev_id);
@@ -1349,7 +1343,8 @@ int vbm_encoder_device_round_run(vbm_encoder *e, int w, const int *lane0, const 
         j.d_packet_bytes = d_packet_bytes ? d_packet_bytes + lane0[m] : nullptr;
         j.big = m == bigm;
         j.timed = prof && m == 3 && first_round;
-        j.depmask = depmask;
+        // (short blocks never follow a type-3 block directly: no wait for the newest big batch)
+        j.depmask = (m < 2 && e->call_big_w >= 0) ? depmask & ~(1u << (e->call_big_w * 4 + 3)) : depmask;
         return j;
     };
     for (int m = 0; m < 4; m++) {

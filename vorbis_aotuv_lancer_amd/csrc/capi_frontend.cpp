@@ -56,7 +56,6 @@ struct vbm_frontend {
     int lane0[4] = {0, 0, 0, 0}, lane_cap[4] = {0, 0, 0, 0}, lanes = 0;
     signed char *d_type = nullptr;        // [S]
     int *d_slot = nullptr, *d_begin_lane = nullptr;       // [S], [lanes]
-    uint8_t *d_hold_call = nullptr;       // [S]
     unsigned long long *d_stats = nullptr;   // [8]
     float *d_blocks_dev = nullptr;        // [nblocks_bufs][lanes][ch][blocksizes[1]]
     std::vector<long long> written;       // samples written per stream (start-of-stream detection without the mirrors)
@@ -701,7 +700,6 @@ extern "C" int vbm_frontend_encode_rounds_device(vbm_frontend *fe, int nrounds, 
         A(fe->d_type, signed char, (size_t)S);
         A(fe->d_slot, int, (size_t)S);
         A(fe->d_begin_lane, int, L);
-        A(fe->d_hold_call, uint8_t, (size_t)S);
         A(fe->d_stats, unsigned long long, 8);
         A(fe->d_blocks_dev, float, (size_t)fe->nblocks_bufs * L * ch * bs1);
 #undef A
@@ -723,7 +721,6 @@ extern "C" int vbm_frontend_encode_rounds_device(vbm_frontend *fe, int nrounds, 
         fe->dirty = false;
         fe->pending_steps = 0;
     }
-    if ((err = hipMemsetAsync(fe->d_hold_call, 0, (size_t)S, q)) != hipSuccess) return vbm_set_hip_error(err, "hipMemsetAsync(hold)");
     for (int r = 0; r < nrounds; r++) {
         int w, ws_lanes;
         int *d_sid, *counts_ws;
@@ -742,7 +739,6 @@ extern "C" int vbm_frontend_encode_rounds_device(vbm_frontend *fe, int nrounds, 
         R.first_round = r == 0;
         R.count = counts_ws;        // the workspace's own counts: what the round's kernels (and graphs) read
         R.slot = fe->d_slot;
-        R.hold = fe->d_hold_call;
         R.stream_id = d_sid;
         R.wflags = d_wf;
         R.begin = fe->d_begin_lane;

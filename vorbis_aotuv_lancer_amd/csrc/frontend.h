@@ -55,10 +55,9 @@ struct vbm_fe_decision {
 // [lane0[m], lane0[m] + cap[m]) of the round's lists and of the encoder workspace behind them.
 struct vbm_fe_round {
     int lane0[4], cap[4];
-    int first_round;             // first round of a call: its type-3 streams are held for the call's later rounds
+    int first_round;             // first round of a call (its long blocks form the call's big batch)
     int *count;                  // [4] device: blocks of each type this round (<= cap)
     int *slot;                   // [S] lane of the stream's block this round, -1 none
-    uint8_t *hold;               // [S] streams left alone for the rest of the call
     int *stream_id;              // [lanes]  (the encoder workspace's own list)
     uint8_t *wflags;             // [lanes]
     int *begin;                  // [lanes] first sample of the block in its stream's buffer

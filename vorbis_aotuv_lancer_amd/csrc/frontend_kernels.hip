@@ -566,22 +566,21 @@ __global__ void k_fe_decide(vbm_fe_state f, const vbm_setup *__restrict__ setup,
 
 // ---- rounds built on the device ----------------------------------------------------------------------------
 // k_fe_classify: which block type would every stream deliver now (-1: none)?  Nothing is changed.
-__global__ void k_fe_classify(vbm_fe_state f, const vbm_setup *__restrict__ setup, const uint8_t *__restrict__ hold,
-                              signed char *__restrict__ type)
+__global__ void k_fe_classify(vbm_fe_state f, const vbm_setup *__restrict__ setup, signed char *__restrict__ type)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= f.S) return;
     vbm_fe_decision d;
     d.ready = 0;
-    if (!hold[s]) fe_decide_one<false>(f, setup, s, d);
+    fe_decide_one<false>(f, setup, s, d);
     type[s] = d.ready ? (signed char)(d.block_mode & 3) : (signed char)-1;
 }
 
 // k_fe_plan (one workgroup): lanes for the blocks of a round.  Block type m owns the fixed lane region
 // [lane0[m], lane0[m] + cap[m]); inside it the streams follow in ascending order.  A stream whose type's region is
 // full keeps its block for the next round (rounds may be deferred: blocks and packets do not depend on when they
-// run).  Streams that deliver a block of the big type (3) in the first round of a call are left alone for the
-// rest of the call (hold), so that no later batch of the call has to wait for the big one.
+// run).  A stream that has fallen behind (a burst of short blocks takes eight rounds per 1024 samples) delivers a
+// block in every round of a call until it has caught up.
 __global__ __launch_bounds__(1024) void k_fe_plan(vbm_fe_round r, const signed char *__restrict__ type, int S)
 {
     __shared__ int s_part[16][4];
@@ -615,7 +614,6 @@ __global__ __launch_bounds__(1024) void k_fe_plan(vbm_fe_round r, const signed c
                 if (rank < r.cap[t]) slot = r.lane0[t] + rank;
             }
             r.slot[s] = slot;
-            if (slot >= 0 && t == 3 && r.first_round) r.hold[s] = 1;
         }
         __syncthreads();
         if (threadIdx.x < 4) {
@@ -797,7 +795,7 @@ extern "C" int vbm_fe_launch_round_plan(const vbm_fe_state *f, const vbm_setup *
                                         hipStream_t st)
 {
     const dim3 g((unsigned)((f->S + 63) / 64));
-    hipLaunchKernelGGL(k_fe_classify, g, dim3(64), 0, st, *f, d_setup, r->hold, d_type);
+    hipLaunchKernelGGL(k_fe_classify, g, dim3(64), 0, st, *f, d_setup, d_type);
     hipLaunchKernelGGL(k_fe_plan, dim3(1), dim3(1024), 0, st, *r, d_type, f->S);
     hipLaunchKernelGGL(k_fe_commit, g, dim3(64), 0, st, *f, d_setup, *r, d_dec);
     hipLaunchKernelGGL(k_fe_blank, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, *r, d_packet_bytes, lanes);

@@ -275,20 +275,20 @@ class FrontEnd:
         later).  They live in a ring of three sets owned by this object."""
         dev = device or torch.device("cuda", torch.cuda.current_device())
         lanes = self.device_lanes
-        ring = getattr(self, "_dring", None)
-        if ring is None or self._dring_key != (nrounds, dev):
-            if ring is not None:
-                self.join()
-                torch.cuda.synchronize(dev)
+        rings = getattr(self, "_drings", None)
+        if rings is None:
+            rings = self._drings = {}
+            self._dring_dev = dev
+        if (nrounds, dev) not in rings:      # one ring of three sets per round count (callers may vary it from call to call)
             n = nrounds * lanes
-            self._dring = [(torch.zeros((n, C.sizeof(PacketInfo)), dtype=torch.uint8, device=dev),
-                            torch.empty((n, self.enc.max_packet_bytes), dtype=torch.uint8, device=dev),
-                            torch.full((n,), -2, dtype=torch.int32, device=dev),
-                            torch.zeros((nrounds, 4), dtype=torch.int32, device=dev)) for _ in range(3)]
-            self._dring_key, self._dring_at = (nrounds, dev), 0
-        at = self._dring_at
-        self._dring_at = (at + 1) % 3
-        info, packets, nbytes, counts = self._dring[at]
+            rings[(nrounds, dev)] = [[(torch.zeros((n, C.sizeof(PacketInfo)), dtype=torch.uint8, device=dev),
+                                       torch.empty((n, self.enc.max_packet_bytes), dtype=torch.uint8, device=dev),
+                                       torch.full((n,), -2, dtype=torch.int32, device=dev),
+                                       torch.zeros((nrounds, 4), dtype=torch.int32, device=dev)) for _ in range(3)], 0]
+        ring = rings[(nrounds, dev)]
+        at = ring[1]
+        ring[1] = (at + 1) % 3
+        info, packets, nbytes, counts = ring[0][at]
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         check(lib.vbm_frontend_encode_rounds_device(self._h, nrounds, packets.data_ptr(), nbytes.data_ptr(), info.data_ptr(),
                                                     counts.data_ptr(), 1 if lazy else 0, st),
@@ -304,10 +304,10 @@ class FrontEnd:
 
     def close(self):
         if self._h:
-            if getattr(self, "_dring", None) is not None:
+            if getattr(self, "_drings", None) is not None:
                 self.join()
-                torch.cuda.synchronize(self._dring_key[1])
-                self._dring = None
+                torch.cuda.synchronize(self._dring_dev)
+                self._drings = None
             if getattr(self, "_ring", None) is not None:      # nothing may still be writing the ring
                 self.join()
                 torch.cuda.synchronize(self._ring_dev)
