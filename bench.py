@@ -324,6 +324,7 @@ def main():
         barrier()
         dt_local = time.perf_counter() - t0
         end_stats = fe.device_stats() if DEVICE_ROUNDS else None
+        counting[0] = False
         # stage times: a few more steps with HIP events between the stage kernels (outside the timed region: the
         # device-built rounds run as HIP graphs, which have no room for events; with timing on they are launched
         # kernel by kernel)

@@ -2,7 +2,7 @@
 """Turn gpurun_out/final/ (tools/gpu_profile.sh) into the committed artifacts:
    profiles/<round>/bench_default.json, kernel_stats.csv, pmc_hbm_traffic.csv and profiles/pmc_traffic.json
    (per-stage HBM bytes per launch that bench.py reports as roofline.traffic)."""
-import csv, json, os, re, sqlite3, sys, collections, statistics
+import csv, json, os, re, sqlite3, subprocess, sys, collections, statistics
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "final")
@@ -11,7 +11,7 @@ dst = os.path.join(ROOT, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
 
 STAGE_OF = [("k_window_mdct", "window_mdct"), ("k_window_fft_log", "window_fft_log"), ("k_to_tiled", "transpose"),
-            ("k_prologue", "prologue"), ("k_nm_", "noisemask"), ("k_tm_", "tonemask"), ("k_mix", "offset_and_mix"),
+            ("k_prologue", "prologue"), ("k_nm_", "noisemask"), ("k_tm_", "tonemask"), ("k_tonemask", "tonemask"), ("k_zero_u128", "pack"), ("k_mix", "offset_and_mix"),
             ("k_floor_prep", "floor_fit"), ("k_floor_fit", "floor_fit"), ("k_floor_interp", "floor_fit"),
             ("k_floor_encode", "floor_encode"), ("k_floor_render", "floor_encode"), ("k_block_state", "offset_and_mix"),
             ("k_nonzero_propagate", "pack"), ("k_bitrate_choose", "pack"), ("k_blob_gather", "packet_out"),
@@ -76,10 +76,13 @@ with open(os.path.join(dst, "pmc_hbm_traffic.csv"), "w", newline="") as f:
         stage_bytes[st] += by * mult
         w.writerow([k, st, n, fk, wk, round(by)])
 cfg = bench["config"]
-json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `bench.py --steps 6 --warmup 2`; "
+commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `bench.py --only block --steps 6 --warmup 2` "
+                   "(per-block leg: every launch is one step's long blocks); "
                    "hbm bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB (gfx950 FETCH_SIZE tallies 128-B requests at 64 B, "
                    "MI355X_MICROARCH.md HBM section); median over launches, summed over the kernels of a stage.",
-           "channel_blocks_per_step": cfg["channel_blocks_per_step"], "sub_batches": bench.get("sub_batches", 1),
+           "commit": commit, "mode": "per_block_path",
+           "channel_blocks_per_step": cfg.get("channel_blocks_per_step", 32768), "sub_batches": bench.get("sub_batches", 1),
            "hbm_bytes_per_launch": {k: round(v) for k, v in stage_bytes.items()}},
           open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
 print("wrote", dst, "and profiles/pmc_traffic.json")
