@@ -7,7 +7,10 @@ import csv, json, os, re, sqlite3, subprocess, sys, collections, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "final")
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
-dst = os.path.join(ROOT, "profiles", rnd)
+# second argument: where to write (default: the repository's profiles/); the GPU box writes under gpurun_out/ and
+# drops the databases, which are too large to travel back
+out_root = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles")
+dst = os.path.join(out_root, rnd)
 os.makedirs(dst, exist_ok=True)
 
 STAGE_OF = [("k_window_mdct", "window_mdct"), ("k_window_fft_log", "window_fft_log"), ("k_to_tiled", "transpose"),
@@ -76,7 +79,7 @@ with open(os.path.join(dst, "pmc_hbm_traffic.csv"), "w", newline="") as f:
         stage_bytes[st] += by * mult
         w.writerow([k, st, n, fk, wk, round(by)])
 cfg = bench["config"]
-commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+commit = sys.argv[3] if len(sys.argv) > 3 else subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
 json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `bench.py --only block --steps 6 --warmup 2` "
                    "(per-block leg: every launch is one step's long blocks); "
                    "hbm bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB (gfx950 FETCH_SIZE tallies 128-B requests at 64 B, "
@@ -84,6 +87,6 @@ json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate pa
            "commit": commit, "mode": "per_block_path",
            "channel_blocks_per_step": cfg.get("channel_blocks_per_step", 32768), "sub_batches": bench.get("sub_batches", 1),
            "hbm_bytes_per_launch": {k: round(v) for k, v in stage_bytes.items()}},
-          open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+          open(os.path.join(out_root, "pmc_traffic.json"), "w"), indent=1)
 print("wrote", dst, "and profiles/pmc_traffic.json")
 for k, v in sorted(stage_bytes.items(), key=lambda x: -x[1]): print(f"  {k:18s} {v/1e6:10.1f} MB/launch")

@@ -12,5 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $OUT/stats.log 2>&1; echo "stats rc=$?"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o f -- python3 $GRAFT_REPO_ROOT/bench.py --only block --steps 6 --warmup 2 --no-cpu-baseline > $OUT/fetch.log 2>&1; echo "fetch rc=$?"
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o w -- python3 $GRAFT_REPO_ROOT/bench.py --only block --steps 6 --warmup 2 --no-cpu-baseline > $OUT/write.log 2>&1; echo "write rc=$?"
-ls -la $OUT $OUT/*/ | head -40
-cat $OUT/bench.json | cut -c1-600
+cd $GRAFT_REPO_ROOT
+python3 tools/collect_profiles.py ${1:-r02} $OUT/profiles $2 && rm -rf $OUT/stats $OUT/fetch $OUT/write
+ls -la $OUT $OUT/profiles/*
+cut -c1-600 $OUT/bench.json
