@@ -1005,8 +1005,12 @@ extern "C" int vbm_launch_prologue(const vbm_batch *b, hipStream_t st)
     hipLaunchKernelGGL(k_prologue, grid_for(b->nsb), dim3(64), 0, st, *b);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
+extern "C" int vbm_launch_noisemask_lds(const vbm_batch *b, hipStream_t st);   // noise_kernels.hip
 extern "C" int vbm_launch_noisemask(const vbm_batch *b, hipStream_t st)
 {
+    static int fused = -1;
+    if (fused < 0) fused = getenv("VBM_NOISE_FUSED") ? atoi(getenv("VBM_NOISE_FUSED")) : 1;
+    if (fused) return vbm_launch_noisemask_lds(b, st);
     const unsigned tiles = (unsigned)((b->ncb + 63) / 64);
     const int nchunks = bin_chunks(b);
     hipLaunchKernelGGL(k_nm_prefix<1>, dim3(tiles, 5), dim3(64), 0, st, *b);
