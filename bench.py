@@ -328,6 +328,8 @@ def main():
         # stage times: a few more steps with HIP events between the stage kernels (outside the timed region: the
         # device-built rounds run as HIP graphs, which have no room for events; with timing on they are launched
         # kernel by kernel)
+        if os.environ.get("VBM_BENCH_NO_STAGE_PASS"):      # kernel traces of the timed region alone (tools/gpu_pcm_trace.sh)
+            PROF_STEPS = 0
         enc.profile_begin(PROF_STEPS * 4)
         for k in range(PROF_STEPS):
             step_pcm(args.warmup + args.steps + k)
@@ -402,7 +404,7 @@ def main():
     if rank == 0:
         def stage_view(r):
             calls = max(r["calls"], 1)
-            per_step = {k: ms_ / r.get("prof_steps", args.steps) for k, ms_ in r["stage_ms"].items()}
+            per_step = {k: ms_ / max(r.get("prof_steps", args.steps), 1) for k, ms_ in r["stage_ms"].items()}
             per_launch = {k: ms_ / calls for k, ms_ in r["stage_ms"].items()}
             cb = r["blocks_prof"] * CHANNELS // calls if r["blocks_prof"] else ncb   # channel-blocks per timed launch
             dominant = max(per_step, key=per_step.get)

@@ -14,7 +14,7 @@ dst = os.path.join(out_root, rnd)
 os.makedirs(dst, exist_ok=True)
 
 STAGE_OF = [("k_window_mdct", "window_mdct"), ("k_window_fft_log", "window_fft_log"), ("k_to_tiled", "transpose"),
-            ("k_prologue", "prologue"), ("k_nm_", "noisemask"), ("k_tm_", "tonemask"), ("k_tonemask", "tonemask"), ("k_zero_u128", "pack"), ("k_mix", "offset_and_mix"),
+            ("k_prologue", "prologue"), ("k_nm_", "noisemask"), ("k_noisemask", "noisemask"), ("k_tm_", "tonemask"), ("k_tonemask", "tonemask"), ("k_zero_u128", "pack"), ("k_mix", "offset_and_mix"),
             ("k_floor_prep", "floor_fit"), ("k_floor_fit", "floor_fit"), ("k_floor_interp", "floor_fit"),
             ("k_floor_encode", "floor_encode"), ("k_floor_render", "floor_encode"), ("k_block_state", "offset_and_mix"),
             ("k_nonzero_propagate", "pack"), ("k_bitrate_choose", "pack"), ("k_blob_gather", "packet_out"),

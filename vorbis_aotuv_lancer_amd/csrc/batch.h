@@ -59,10 +59,8 @@ struct vbm_batch {
     // array's offset inside the slab.
     size_t slab_words;
     size_t sb_slab_words;           // same for the stream-block-lane arrays (partwordT, workvqT)
-    float *mdctT, *logmdctT, *noiseT, *toneT, *logmaskT, *epeakT, *workT;
+    float *mdctT, *logmdctT, *noiseT, *toneT, *logmaskT, *epeakT;
     float *npeakT;                  // [n/partition][L]
-    float *sumT;                    // [5][n][L]  N, X, XX, Y, XY of bark_noise_hybridmp
-    float *ntfixT;                  // [2][256][L]  temp / inmod of aoTuV M7 (noise branch; the seed arrays belong to the tone branch)
     float *poste;                   // [L]
     float *global_ampmax;           // [Ls]
     int *postT;                     // [VIF_POSIT+2][L]  floor posts (fit, then quantised by encode)

@@ -308,19 +308,18 @@ extern "C" int vbm_encoder_create(vbm_encoder **out, vbm_setup_handle *setup, in
         size_t rows = 0;
         auto take = [&](size_t r) { size_t at = rows; rows += r; return at * 64; };
         const size_t o_mdct = take(nmax), o_logmdct = take(nmax), o_noise = take(nmax),
-                     o_tone = take(nmax), o_logmask = take(nmax), o_epeak = take(nmax), o_work = take(nmax),
-                     o_npeak = take(nmax / 8 + 1), o_sum = take((size_t)5 * nmax), o_post = take((size_t)(VBM_VIF_POSIT + 2) * VBM_PACKETBLOBS),
-                     o_fout = take(VBM_VIF_POSIT + 2), o_iwork = take(nmax), o_ntfix = take(512);
+                     o_tone = take(nmax), o_logmask = take(nmax), o_epeak = take(nmax),
+                     o_npeak = take(nmax / 8 + 1), o_post = take((size_t)(VBM_VIF_POSIT + 2) * VBM_PACKETBLOBS),
+                     o_fout = take(VBM_VIF_POSIT + 2), o_iwork = take(nmax);
         b.slab_words = rows * 64;
         float *slab;
         A(slab, float, (L / 64) * b.slab_words);
         b.mdctT = slab + o_mdct; b.logmdctT = slab + o_logmdct;
         b.noiseT = slab + o_noise; b.toneT = slab + o_tone; b.logmaskT = slab + o_logmask;
-        b.epeakT = slab + o_epeak; b.workT = slab + o_work; b.npeakT = slab + o_npeak; b.sumT = slab + o_sum;
+        b.epeakT = slab + o_epeak; b.npeakT = slab + o_npeak;
         b.postT_blob = (int *)(slab + o_post);
         b.postT = b.postT_blob + (size_t)(VBM_PACKETBLOBS / 2) * (VBM_VIF_POSIT + 2) * 64;
         b.floor_outT = (int *)(slab + o_fout); b.iworkT = (int *)(slab + o_iwork);
-        b.ntfixT = slab + o_ntfix;
 
         size_t srows = 0;
         auto stake = [&](size_t r) { size_t at = srows; srows += r; return at * 64; };
@@ -553,8 +552,8 @@ static vbm_batch slice_of(const vbm_batch &f, int sb0, int nsb, uint8_t *d_packe
     if (v.packet_bytes_blob) { v.packet_bytes_blob += sb0; v.choice += sb0; v.packetT_blob += stl * 64 * (size_t)f.max_packet_bytes; }
     const size_t co = ct * f.slab_words;
     v.mdctT += co; v.logmdctT += co; v.noiseT += co; v.toneT += co; v.logmaskT += co;
-    v.epeakT += co; v.workT += co; v.npeakT += co; v.sumT += co;
-    v.postT += co; v.postT_blob += co; v.floor_outT += co; v.iworkT += co; v.ntfixT += co;
+    v.epeakT += co; v.npeakT += co;
+    v.postT += co; v.postT_blob += co; v.floor_outT += co; v.iworkT += co;
     const size_t so = stl * f.sb_slab_words;
     v.partwordT += so; v.workvqT += so; v.m6defT += so; v.vqlenT += so; v.vqoffT += so;
     v.vqcodeT += stl * f.vq_slab_words;

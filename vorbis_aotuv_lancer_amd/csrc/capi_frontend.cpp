@@ -178,7 +178,13 @@ extern "C" int vbm_frontend_create(vbm_frontend **out, vbm_encoder *enc)
         g_vbm_err = "hipHostMalloc(front end) failed";
         return VBM_EHIP;
     }
-    if (hipStreamCreateWithFlags(&fe->q, hipStreamNonBlocking) != hipSuccess ||
+    // The front end's queue: short kernels the rounds of every block type wait for.  VBM_FE_PRIORITY=1: a high-priority
+    // stream (its packets go before those of the batch streams when the command processor picks a queue).
+    int plo = 0, phi = 0;
+    const bool fe_prio = getenv("VBM_FE_PRIORITY") && atoi(getenv("VBM_FE_PRIORITY")) &&
+                         hipDeviceGetStreamPriorityRange(&plo, &phi) == hipSuccess && phi < plo;
+    if ((fe_prio ? hipStreamCreateWithPriority(&fe->q, hipStreamNonBlocking, phi)
+                 : hipStreamCreateWithFlags(&fe->q, hipStreamNonBlocking)) != hipSuccess ||
         hipEventCreateWithFlags(&fe->ev_in, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&fe->ev_out, hipEventDisableTiming) != hipSuccess) {
         vbm_frontend_destroy(fe);

@@ -250,8 +250,6 @@ __global__ __launch_bounds__(NM_THREADS) void k_noisemask(vbm_batch b, const int
     if (lane0 >= ncb) return;
     const int nb = VMIN(NB, ncb - lane0);
     const int tid = (int)threadIdx.x;
-    // the wavefront that walks the running sums: a different one (= SIMD) for the workgroups that share a CU
-    const int scan0 = 64 * ((phases >> 8) == 0 ? (wg & 3) : (phases >> 8) == 1 ? ((wg >> 5) & 3) : (phases >> 8) == 2 ? ((wg ^ (wg >> 5)) & 3) : 0);
 
     const int i1 = p->hy_i1, i2 = p->hy_i2;
     const int fixed = p->noisewindowfixed;
@@ -347,7 +345,7 @@ __global__ __launch_bounds__(NM_THREADS) void k_noisemask(vbm_batch b, const int
                     if (blk < nb) nm_terms(pass == 1 ? lm[r][blk] : wk[r][blk], i, offset, SU + (size_t)blk * 5 * NS, NS);
         }
         __syncthreads();
-        if (tid >= scan0 && tid < scan0 + nb * 5 && (phases & 1)) nm_scan(SU + (size_t)(tid - scan0) * NS, n);
+        if (tid < nb * 5 && (phases & 1)) nm_scan(SU + (size_t)tid * NS, n);
         __syncthreads();
         if (phases & 2) {
 #pragma unroll
@@ -554,7 +552,7 @@ int launch(const vbm_batch *b, hipStream_t st)
 
 // Blocks per workgroup: 2 long blocks (n = 1024: 41 KB of LDS, three workgroups per CU), more of the shorter ones
 // (the rows going out are NB words wide).  n: 128 .. 4096, a multiple of 16.
-extern "C" int vbm_launch_noisemask_lds(const vbm_batch *b, hipStream_t st)
+extern "C" int vbm_launch_noisemask(const vbm_batch *b, hipStream_t st)
 {
     const int n = b->n;
     if ((n & 63) || n < 128 || n > 4096) return -2;     // (M7's scratch rows live in a block's five sum arrays)

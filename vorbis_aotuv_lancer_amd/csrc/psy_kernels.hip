@@ -5,15 +5,12 @@
 //   k_prologue    ampmax tracking of vorbis_analysis_blockout (lib/block.c:649-651,
 //                 _vp_ampmax_decay lib/psy.c:4504-4515), global_ampmax of mapping0_forward
 //                 (lib/mapping0.c:752, 889-901), _postnoise_detection (lib/psy.c:619-648)
-//   k_noisemask   logmdct (lib/mapping0.c:936-950), lb_loudnoise_fix (lib/psy.c:5152-5180),
-//                 _vp_noisemask (lib/psy.c:3770-4074) = bark_noise_hybridmp x2 (:3480-3638),
-//                 ntfix (:3645-3768), compander, M2 post-echo, M8, M9
-//   (_vp_tonemask lives in tone_kernels.hip: a workgroup per group of blocks, seeds in LDS)
+//   (_vp_noisemask and _vp_tonemask live in noise_kernels.hip / tone_kernels.hip: a workgroup per group of
+//   blocks, working set in LDS)
 //   k_mix         _vp_offset_and_mix (lib/psy.c:4274-4502, set_m3p :4148-4272): offset_select 1 for VBR,
 //                 1 / 2 / 0 with bit_managed for managed bitrate, including the aoTuV carried buffers
 //                 lastmdct / tempmdct
-// The order-bound float accumulations (the five prefix sums of bark_noise_hybridmp, the
-// partition sums of M8) stay serial per lane, exactly in source order; table-driven loop
+// The order-bound float accumulations stay serial per lane, exactly in source order; table-driven loop
 // bounds are identical in every lane, so the wave runs them in lockstep and table reads are
 // wave-uniform.  Compiled with -ffp-contract=off; `double` where the C source promotes.
 #include <hip/hip_runtime.h>
@@ -109,494 +106,7 @@ __global__ void k_prologue(vbm_batch b)
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// _vp_noisemask is split into launches so that only what the source's float arithmetic forces to
-// be serial stays serial:
-//   k_nm_prefix<PASS>  the five running sums N, X, XX, Y, XY of bark_noise_hybridmp
-//                      (lib/psy.c:3480-3541).  Each sum is an order-bound chain over the bins, but
-//                      the five chains are independent of one another: blockIdx.y picks the chain,
-//                      so a tile of 64 channel-blocks is walked by five wavefronts.  PASS 1 also
-//                      produces logmdct (lib/mapping0.c:936-950) and lb_loudnoise_fix.
-//   k_nm_solve<PASS>   the per-bin regression solve (lib/psy.c:3543-3636): every bin only reads the
-//                      finished sums, so bins are sliced over blockIdx.y.
-//   k_nm_ntfix         aoTuV M7 (short and transition blocks only), serial over <= 256 bins.
-//   k_nm_post          compander, M2 post-echo, M8, M9: independent per normal-partition, sliced
-//                      over blockIdx.y in units of partitions.
-#define HY_PF 16
-static_assert(HY_PF == 16, "k_nm_prefix keeps the last row of every HY_PF batch as the checkpoint");
-#define NM_C 16     // checkpoint interval of the five running sums (rows NM_C-1, 2*NM_C-1, ... are stored)
-
-struct hy_bounds { int i1, i2, f1, f2; };
-
-// phase limits of the solve loops: table-only conditions, evaluated by the host (setup_host.cpp)
-__device__ __forceinline__ hy_bounds hybrid_bounds(const vbm_psy *p, int fixed)
-{
-    hy_bounds h;
-    h.i1 = p->hy_i1; h.i2 = p->hy_i2;
-    h.f1 = (fixed > 0) ? p->hy_f1 : 0;
-    h.f2 = (fixed > 0) ? p->hy_f2 : 0;
-    return h;
-}
-
-template <int PASS, int CHAIN>
-__device__ __forceinline__ void prefix_chain(const vbm_batch &b, const vbm_psy *p, const size_t tb, const int sid, const int col)
-{
-    const int n = p->n;
-    const float offset = (PASS == 1) ? 140.f : 0.f;
-    const float *__restrict__ src = (PASS == 1) ? b.mdctT : b.workT;
-    // the five sums of a bin sit next to each other: sumT[(bin * 5 + chain)][64] (the solve reads all five of a
-    // window edge at once: one 1280-byte run instead of five rows 256 KB apart)
-    float *__restrict__ dst = b.sumT + (size_t)CHAIN * 64;
-    float *__restrict__ logmdct = b.logmdctT;
-    float acc = 0.f, x = 0.f;
-    double hi_th = 0;
-    const int n25p = p->n25p, n75p = p->n75p;
-    const int rb = p->hy_rb;
-
-    // one bin: logmdct (pass 1), the term of this chain, the running sum
-    auto bin = [&](float v, const int k) {
-        if (PASS == 1) {
-            v = (float)((double)vbm_todB(v) + .345);   // logmdct, lib/mapping0.c:936
-            if (CHAIN == 0) {
-                T(logmdct, k) = v;
-                if (k >= n25p && k < n75p) hi_th += (v > -130) ? (double)v : -130.;
-            }
-        }
-        float y = v + offset;
-        if (y < 1.f) y = 1.f;
-        float w = y * y;
-        if (k == 0) {
-            // first element, lib/psy.c:3497-3507: half weight, x = 0 (X takes w, XX and XY nothing)
-            w = (float)((double)w * .5);
-            if (CHAIN == 0 || CHAIN == 1) acc += w;
-            if (CHAIN == 3) acc += w * y;
-        } else {
-            if (CHAIN == 0) acc += w;
-            if (CHAIN == 1) acc += w * x;
-            if (CHAIN == 2) acc += w * x * x;
-            if (CHAIN == 3) acc += w * y;
-            if (CHAIN == 4) acc += w * x * y;
-        }
-        x += 1.f;
-    };
-    // rows below rb (a multiple of HY_PF): every row is kept, for the mirrored window edges
-    int i = 0;
-    for (; i < rb && i < n; i += HY_PF) {
-        float fv[HY_PF];
-#pragma unroll
-        for (int u = 0; u < HY_PF; u++) fv[u] = T(src, (i + u < n) ? i + u : n - 1);   // unconditional, clamped
-#pragma unroll
-        for (int u = 0; u < HY_PF; u++)
-            if (i + u < n) {
-                bin(fv[u], i + u);
-                T(dst, (i + u) * 5) = acc;
-            }
-    }
-    // the rest: only the last row of a batch is kept, as a checkpoint the solve restarts its running sums from
-    // (k_nm_solve).  Loads and stores retire in order, so the next batch's loads are issued BEFORE this batch's
-    // stores (a fixed number of them): the wait for the loads then does not include the stores.
-    if (i < n) {
-        float cur[HY_PF];
-#pragma unroll
-        for (int u = 0; u < HY_PF; u++) cur[u] = T(src, (i + u < n) ? i + u : n - 1);
-        for (; i < n; i += HY_PF) {
-            float nxt[HY_PF];
-            const int in = (i + HY_PF < n) ? i + HY_PF : i;
-#pragma unroll
-            for (int u = 0; u < HY_PF; u++) nxt[u] = T(src, (in + u < n) ? in + u : n - 1);
-#pragma unroll
-            for (int u = 0; u < HY_PF; u++)
-                if (i + u < n) bin(cur[u], i + u);
-            T(dst, (((i + HY_PF < n) ? i + HY_PF : n) - 1) * 5) = acc;
-#pragma unroll
-            for (int u = 0; u < HY_PF; u++) cur[u] = nxt[u];
-        }
-    }
-
-    if (PASS == 1 && CHAIN == 0) {
-        // lb_loudnoise_fix (lib/psy.c:5152-5180)
-        float noise_compand_level = b.st.lowcomp[col];
-        const int lW_block_mode = b.st.lW_block_mode[sid];
-        if (p->m_val < 0.5) noise_compand_level = -1;
-        else if (p->normal_thresh > .45) noise_compand_level = -1;
-        else if ((b.block_mode == 2 && lW_block_mode == 3) || (b.block_mode == 3 && lW_block_mode == 2)) {
-            hi_th /= n;
-            if (hi_th > -40.) noise_compand_level = -1;
-            else if (hi_th < -50.) noise_compand_level = 1.f;
-            else noise_compand_level = (float)(1. - ((hi_th + 50) / 10));
-        }
-        b.st.lowcomp[col] = noise_compand_level;
-    }
-}
-
-template <int PASS>
-__global__ void k_nm_prefix(vbm_batch b)
-{
-    const int lane = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lane >= vbm_ncb(b)) return;
-    const size_t tb = TB(b, lane);
-    const vbm_psy *p = psy_of(b);
-    const int sb = lane / b.ch, c = lane - sb * b.ch;
-    const int sid = b.stream_id[sb];
-    const int col = sid * b.ch + c;
-    switch (blockIdx.y) {
-    case 0: prefix_chain<PASS, 0>(b, p, tb, sid, col); break;
-    case 1: prefix_chain<PASS, 1>(b, p, tb, sid, col); break;
-    case 2: prefix_chain<PASS, 2>(b, p, tb, sid, col); break;
-    case 3: prefix_chain<PASS, 3>(b, p, tb, sid, col); break;
-    default: prefix_chain<PASS, 4>(b, p, tb, sid, col); break;
-    }
-}
-
-// The solve needs the five running sums at the two edges of every bin's window.  The edges only move
-// forward with the bin index, so instead of reading stored sums (five floats per edge per bin, 20 loads per
-// bin in pass 2: 4.4 GB per step through HBM) each edge keeps ITS OWN running sums in registers and adds the
-// terms of the bins it passes — the same additions in the same order as k_nm_prefix, hence the same bits.
-// A slice of bins starts its edges from the nearest stored checkpoint row below (every NM_C-th row); rows
-// below hy_rb are all stored, for the mirrored edges (-lo) of the first bins, which move backwards.
-struct acc5 { float n, x, xx, y, xy; int pos; };   // sums after bin `pos`
-struct hy_abd { float A, B, D; };
-
-__device__ __forceinline__ void acc_load(acc5 &a, const float *__restrict__ sum, const size_t tb, const int k)
-{
-    const float *__restrict__ R = sum + tb + (size_t)k * 5 * 64;
-    a.n = R[0]; a.x = R[64]; a.xx = R[128]; a.y = R[192]; a.xy = R[256];
-    a.pos = k;
-}
-
-// sums after bin `target` (lib/psy.c:3509-3541 for the terms; k >= 1 here: row 0 is always stored)
-template <int PASS>
-__device__ __forceinline__ void acc_seek(acc5 &a, const int target, const float *__restrict__ src,
-                                         const float *__restrict__ sum, const size_t tb, const int rb)
-{
-    const float offset = (PASS == 1) ? 140.f : 0.f;
-    if (target < rb) { acc_load(a, sum, tb, target); return; }
-    if (a.pos < 0 || target < a.pos || target - a.pos >= 2 * NM_C) acc_load(a, sum, tb, ((target + 1) & ~(NM_C - 1)) - 1);
-    while (a.pos < target) {
-        const int k = ++a.pos;
-        float y = src[tb + (size_t)k * 64] + offset;
-        if (y < 1.f) y = 1.f;
-        const float w = y * y, xk = (float)k;
-        a.n += w;
-        a.x += w * xk;
-        a.xx += w * xk * xk;
-        a.y += w * y;
-        a.xy += w * xk * y;
-    }
-}
-
-// window sums and the regression terms of one bin (lib/psy.c:3549-3560 mirrored, :3571-3582 plain)
-__device__ __forceinline__ hy_abd hybrid_abd(const acc5 &H, const acc5 &L, const bool mirror)
-{
-    float tN, tX, tXX, tY, tXY;
-    if (mirror) {
-        tN = H.n + L.n; tX = H.x - L.x; tXX = H.xx + L.xx; tY = H.y + L.y; tXY = H.xy - L.xy;
-    } else {
-        tN = H.n - L.n; tX = H.x - L.x; tXX = H.xx - L.xx; tY = H.y - L.y; tXY = H.xy - L.xy;
-    }
-    hy_abd r;
-    r.A = tY * tXX - tX * tXY;
-    r.B = tN * tXY - tX * tY;
-    r.D = tN * tXX - tX * tX;
-    return r;
-}
-
-// one window: edges hi and lo (mirror: the lower edge is the stored row -lo)
-template <int PASS>
-__device__ __forceinline__ hy_abd hybrid_window(acc5 &H, acc5 &L, const int lo, const int hi, const bool mirror,
-                                                const float *__restrict__ src, const float *__restrict__ sum,
-                                                const size_t tb, const int rb)
-{
-    acc_seek<PASS>(H, hi, src, sum, tb, rb);
-    if (mirror) {
-        acc5 M;
-        acc_load(M, sum, tb, -lo);
-        return hybrid_abd(H, M, true);
-    }
-    acc_seek<PASS>(L, lo, src, sum, tb, rb);
-    return hybrid_abd(H, L, false);
-}
-
-template <int PASS>
-__global__ void k_nm_solve(vbm_batch b, int nchunks)
-{
-    const int lane = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lane >= vbm_ncb(b)) return;
-    const size_t tb = TB(b, lane);
-    const vbm_psy *p = psy_of(b);
-    const int n = p->n;
-    const int c0 = (int)((long)n * blockIdx.y / nchunks), c1 = (int)((long)n * (blockIdx.y + 1) / nchunks);
-    const float offset = (PASS == 1) ? 140.f : 0.f;
-    const int fixed = (PASS == 1) ? -1 : p->noisewindowfixed;
-    const hy_bounds h = hybrid_bounds(p, fixed);
-    const int *__restrict__ bark_lo = p->bark_lo, *__restrict__ bark_hi = p->bark_hi;   // hoisted: see note at psy_of
-    const int rb = p->hy_rb;
-    const float *__restrict__ sum = b.sumT;
-    float *__restrict__ noise = b.noiseT;
-    float *__restrict__ work = b.workT;
-    // pass 2 reads `work` along its window edges (bins of other slices), so its own result
-    // logmdct - work (lib/psy.c:3812) goes to a second array: logmaskT is free until _vp_offset_and_mix
-    float *__restrict__ work2 = b.logmaskT;
-    const float *__restrict__ logmdct = b.logmdctT;
-    const float *__restrict__ src = (PASS == 1) ? b.logmdctT : b.workT;   // what k_nm_prefix<PASS> summed
-
-    // the tail loops (lib/psy.c:3587-3591, :3631-3635) keep A, B, D of the last bin solved before them
-    hy_abd tail; tail.A = 0.f; tail.B = 0.f; tail.D = 1.f;
-    if (c1 > h.i2 && h.i2 > 0) {
-        const int t = h.i2 - 1;
-        acc5 Ht, Lt;
-        Ht.pos = Lt.pos = -1;
-        tail = hybrid_window<PASS>(Ht, Lt, bark_lo[t], bark_hi[t], t < h.i1, src, sum, tb, rb);
-    }
-    hy_abd ftail = tail;
-    if (fixed > 0 && c1 > h.f2 && h.f2 > 0) {
-        const int t = h.f2 - 1, hi = t + fixed / 2, lo = hi - fixed;
-        acc5 Ht, Lt;
-        Ht.pos = Lt.pos = -1;
-        ftail = hybrid_window<PASS>(Ht, Lt, lo, hi, t < h.f1, src, sum, tb, rb);
-    }
-
-    acc5 H, L, HF, LF;
-    H.pos = L.pos = HF.pos = LF.pos = -1;
-    for (int i = c0; i < c1; i++) {
-        const float x = (float)i;   // the source's x += 1.f from 0 is exact below 2^24
-        hy_abd v = tail;
-        if (i < h.i2) v = hybrid_window<PASS>(H, L, bark_lo[i], bark_hi[i], i < h.i1, src, sum, tb, rb);
-        float R = (v.A + x * v.B) / v.D;
-        if (R < 0.f) R = 0.f;
-        float nz = R - offset;
-        if (PASS == 1) {
-            T(noise, i) = nz;
-            T(work, i) = T(logmdct, i) - nz;                    // lib/psy.c:3807
-        } else {
-            if (fixed > 0) {
-                hy_abd w = ftail;
-                if (i < h.f2) {
-                    const int hi = i + fixed / 2, lo = hi - fixed;
-                    w = hybrid_window<PASS>(HF, LF, lo, hi, i < h.f1, src, sum, tb, rb);
-                }
-                R = (w.A + x * w.B) / w.D;
-                if (R - offset < nz) nz = R - offset;
-            }
-            T(noise, i) = nz;
-            T(work2, i) = T(logmdct, i) - T(work, i);           // lib/psy.c:3812
-        }
-    }
-}
-
-// aoTuV M7, lib/psy.c:3645-3768.  temp/inmod: 256-entry per-lane scratch (ntfixT)
-__device__ __forceinline__ void ntfix(const vbm_batch &b, const vbm_psy *p, int lane, const float *spectral, float *noise)
-{
-    const size_t tb = TB(b, lane);
-    int i, j, k;
-    int n = p->n;
-    int nx = p->tonefix_end;
-    float *temp = b.ntfixT, *inmod = b.ntfixT + (size_t)256 * 64;
-    float limit = fabsf(p->noiseoffset[1][0]);
-
-    if (!nx) return;
-
-    for (i = 0; i < 256; i++) { T(temp, i) = 0.f; T(inmod, i) = 0.f; }
-
-    if (b.block_mode <= 1) {
-        const int freq_upc = 3;
-        const int freq_unc = 4;
-        int nxplus = nx + freq_unc;
-        float tolerance = 9.f;
-        float strength = .6f;
-        if (n == 256) tolerance = 15.f;
-        if (nxplus > n) {
-            nx = n;
-            nxplus = n - freq_unc;
-        }
-
-        for (i = 0; i < nxplus; i++) {
-            float sp = T(spectral, i);
-            if (sp < -70) T(inmod, i) = (float)(-70 + (double)(sp + 70) * .1);
-            else T(inmod, i) = sp;
-        }
-        for (i = freq_unc; i < nx; i++) {
-            if ((T(spectral, i) > T(spectral, i - 1)) && (T(spectral, i) > T(spectral, i + 1))) {
-                int ps = i - 1;
-                int pe = i + 1;
-                int upper = i - freq_upc;
-                int under = i + freq_unc;
-                for (j = ps; j > upper; j--) {
-                    if (T(spectral, j + 1) < T(spectral, j)) break;
-                    ps = j;
-                }
-                for (j = pe; j < under; j++) {
-                    if (T(spectral, j - 1) < T(spectral, j)) break;
-                    pe = j;
-                }
-                {
-                    float ss = T(inmod, i) - T(inmod, ps);
-                    ss = VMAX(ss, T(inmod, i) - T(inmod, pe));
-                    if (ss > tolerance) {
-                        if (T(spectral, i) > T(noise, i)) {
-                            ss -= tolerance;
-                            ss *= strength;
-                        }
-                        for (j = ps; j <= pe; j++) {
-                            T(temp, j) = VMAX(ss, T(temp, j));
-                            if (T(temp, j) < 0) T(temp, j) = 0;
-                        }
-                    }
-                }
-                i = pe;
-            }
-        }
-        for (i = freq_unc - 1; i < nx; i++) {
-            float test = VMIN(p->ntfix_noiseoffset[i], p->noiseoffset[1][i] + limit);
-            if (T(temp, i) > test) T(temp, i) = test;
-            T(noise, i) -= T(temp, i);
-        }
-    } else if (b.block_mode == 2) {
-        for (i = 0, k = 0; i < nx; i += 8, k++) {
-            double na = 0;
-            for (j = 0; j < 8; j++) na += T(noise, i + j);
-            na /= 8;
-            T(temp, k) = (float)na;
-        }
-        nx /= 8;
-        for (i = 3; i < nx; i++) {
-            if ((T(temp, i) > T(temp, i - 1)) && (T(temp, i) > T(temp, i + 1))) {
-                int a = 0, bb = 0;
-                float thres = 0;
-                if (T(temp, i - 1) > T(temp, i - 2)) {
-                    thres = T(temp, i - 2);
-                    a = i - 3;
-                } else {
-                    thres = T(temp, i - 1);
-                    a = i - 2;
-                }
-                bb = i + 3;
-                thres = T(temp, i) - thres;
-                if ((double)thres > 2.) {
-                    int eightimes = i * 8;
-                    float test = VMIN(p->ntfix_noiseoffset[eightimes], p->noiseoffset[1][eightimes] + limit);
-                    thres = VMIN(thres - 2, test);
-                    a *= 8;
-                    bb *= 8;
-                    for (j = a; j <= bb; j++) T(noise, j) -= thres;
-                }
-            }
-        }
-    }
-}
-
-__global__ void k_nm_ntfix(vbm_batch b)
-{
-    const int lane = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lane >= vbm_ncb(b)) return;
-    ntfix(b, psy_of(b), lane, b.logmdctT, b.logmaskT);   // pass 2's logmdct - work: see k_nm_solve
-}
-
-__global__ void k_nm_post(vbm_batch b, int nchunks)
-{
-    const int lane = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lane >= vbm_ncb(b)) return;
-    const size_t tb = TB(b, lane);
-    const vbm_setup *s = b.setup;
-    const vbm_psy *p = psy_of(b);
-    const int n = p->n;
-    const int sb = lane / b.ch, c = lane - sb * b.ch;
-    const int sid = b.stream_id[sb];
-    const int col = sid * b.ch + c;
-    const int partition = (p->normal_p ? p->normal_partition : 16);
-    const int nparts = (n + partition - 1) / partition;
-    const int k0 = (int)((long)nparts * blockIdx.y / nchunks), k1 = (int)((long)nparts * (blockIdx.y + 1) / nchunks);
-    const int c0 = k0 * partition, c1 = VMIN(k1 * partition, n);
-    int i, j, k;
-
-    float *logmdct = b.logmdctT, *logmask = b.noiseT, *work = b.logmaskT /* k_nm_solve<2> */, *epeak = b.epeakT, *npeak = b.npeakT;
-    const float noise_compand_level = b.st.lowcomp[col];
-    const float *__restrict__ noisecompand = p->noisecompand, *__restrict__ noisecompand_high = p->noisecompand_high;
-    const int *__restrict__ stn_compand = s->stn_compand;
-    const float *__restrict__ noiseoffset1 = p->noiseoffset[1];
-    const int min_nn_lp = p->min_nn_lp;
-
-    // noise compand & aoTuV M5 extension & tone peak, and M9 with it: M9 (lib/psy.c:4058-4072) replaces the tone
-    // peak of every bin by a value that depends on that peak, logmdct and lastmdct only — nothing in between
-    // reads the intermediate peak — so the final value is stored here and the bins are walked once.  Eight bins'
-    // inputs are read before anything is written (loads and stores retire in order).
-    {
-        const int thter = (noise_compand_level > 0) ? p->n33p : 0;
-        const float *lastmdct = b.st.mblock + (size_t)(col >> 6) * b.st.slab_words + (col & 63);
-        const int m9_end = (b.block_mode > 1) ? p->tonecomp_endp : 0;
-        for (i = c0; i < c1; i += 8) {
-            float lmk[8], wvv[8], lmd[8], lst[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int ii = (i + u < c1) ? i + u : c1 - 1;
-                lmk[u] = T(logmask, ii);
-                wvv[u] = T(work, ii);
-                lmd[u] = T(logmdct, ii);
-                lst[u] = (ii < m9_end) ? lastmdct[(size_t)ii * 64] : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int ii = i + u;
-                if (ii < c1) {
-                    int dB = (int)((double)lmk[u] + .5);
-                    if (dB >= VBM_NOISE_COMPAND_LEVELS) dB = VBM_NOISE_COMPAND_LEVELS - 1;
-                    if (dB < 0) dB = 0;
-                    const float wv = wvv[u];
-                    const float ep = wv + stn_compand[dB];
-                    if (ii < thter)
-                        T(logmask, ii) = wv + noisecompand[dB] -
-                                         ((noisecompand[dB] - noisecompand_high[dB]) * noise_compand_level);
-                    else
-                        T(logmask, ii) = wv + noisecompand[dB];
-                    float e = 0.f;
-                    if (ii < m9_end) {
-                        float temp = lmd[u] - ep;
-                        if (temp >= 12.f) {
-                            float mi = lmd[u] - lst[u];
-                            if (mi >= 1) e = mi;
-                        }
-                    }
-                    T(epeak, ii) = e;
-                }
-            }
-        }
-    }
-
-    for (k = k0; k < k1; k++) T(npeak, k) = 0.f;
-
-    // reduction of post-echo (postprocessing of aoTuV M2)
-    const float poste = b.poste[lane];
-    if (poste > 0) {
-        for (k = k0, i = c0; k < k1 && i < min_nn_lp; i += partition, k++) {
-            float temp = VMIN(VMIN(poste, 30.f), noiseoffset1[i] + 30.f);
-            if (temp <= 0) continue;
-            T(npeak, k) = -1.f;
-            for (j = 0; j < partition; j++) T(logmask, i + j) -= temp;
-        }
-    }
-
-    // M8
-    for (k = k0, i = c0; k < k1 && i < min_nn_lp; i += partition, k++) {
-        const float nt = 4;
-        float o = noiseoffset1[i + partition - 1] + 6;
-        float me = 0;
-        float avge = 0;
-
-        if (o <= 0) continue;
-        if ((double)T(npeak, k) < -0.5) continue;
-
-        for (j = 0; j < partition; j++) {
-            float temp = T(logmdct, i + j) - T(logmask, i + j);
-            if (me < temp) me = temp;
-            avge += T(logmdct, i + j);
-        }
-        if (avge < (-95 * partition)) continue;
-
-        if (me < nt) T(npeak, k) = (VMIN(o, nt - me)) / nt;
-    }
-
-}
-
+// (_vp_noisemask: noise_kernels.hip)
 // (_vp_tonemask: tone_kernels.hip)
 
 // ---------------------------------------------------------------------------------------------
@@ -1003,22 +513,6 @@ static inline int bin_chunks(const vbm_batch *b)
 extern "C" int vbm_launch_prologue(const vbm_batch *b, hipStream_t st)
 {
     hipLaunchKernelGGL(k_prologue, grid_for(b->nsb), dim3(64), 0, st, *b);
-    return hipGetLastError() == hipSuccess ? 0 : -2;
-}
-extern "C" int vbm_launch_noisemask_lds(const vbm_batch *b, hipStream_t st);   // noise_kernels.hip
-extern "C" int vbm_launch_noisemask(const vbm_batch *b, hipStream_t st)
-{
-    static int fused = -1;
-    if (fused < 0) fused = getenv("VBM_NOISE_FUSED") ? atoi(getenv("VBM_NOISE_FUSED")) : 1;
-    if (fused) return vbm_launch_noisemask_lds(b, st);
-    const unsigned tiles = (unsigned)((b->ncb + 63) / 64);
-    const int nchunks = bin_chunks(b);
-    hipLaunchKernelGGL(k_nm_prefix<1>, dim3(tiles, 5), dim3(64), 0, st, *b);
-    hipLaunchKernelGGL(k_nm_solve<1>, dim3(tiles, (unsigned)nchunks), dim3(64), 0, st, *b, nchunks);
-    hipLaunchKernelGGL(k_nm_prefix<2>, dim3(tiles, 5), dim3(64), 0, st, *b);
-    hipLaunchKernelGGL(k_nm_solve<2>, dim3(tiles, (unsigned)nchunks), dim3(64), 0, st, *b, nchunks);
-    if (b->block_mode <= 2) hipLaunchKernelGGL(k_nm_ntfix, dim3(tiles), dim3(64), 0, st, *b);
-    hipLaunchKernelGGL(k_nm_post, dim3(tiles, (unsigned)nchunks), dim3(64), 0, st, *b, nchunks);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 static const size_t kMixTempBytes = (size_t)256 * 64 * sizeof(float);   // impulse blocks: tempmdct columns in LDS
