@@ -231,32 +231,58 @@ __global__ void k_floor_fit(vbm_batch b, int lpw)
         memo[i] = -1;
     }
 
-    // accumulate_fit over every minimal division (lib/floor1.c:625-628)
-    for (int seg = 0; seg < posts - 1; seg++) {
-        int x0 = look->sorted_index[seg], x1 = look->sorted_index[seg + 1];
+    // accumulate_fit over every minimal division (lib/floor1.c:427-475, :625-628) in ONE walk over the lane's row,
+    // four 16-byte pieces in flight (a lane's loads are a chain of round trips to L2 otherwise: ~130 of them).  A
+    // segment takes the bins sorted_index[seg] .. min(sorted_index[seg + 1], n - 1), both ends included: a post's
+    // own bin counts for the segment on either side.
+    {
+        const int nseg = posts - 1;
+        for (int seg = 0; seg < nseg; seg++)
+            for (int f = 0; f < 10; f++) fits.set(seg, f, 0);
+        int seg = 0, end = look->sorted_index[1] >= n ? n - 1 : look->sorted_index[1];
         int xa = 0, ya = 0, x2a = 0, xya = 0, na = 0, xb = 0, yb = 0, x2b = 0, xyb = 0, nb = 0;
-        if (x1 >= n) x1 = n - 1;
-        // eight bins per 16-byte load, unpacked with constant shifts
-        for (int blk = x0 >> 3; blk <= x1 >> 3; blk++) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(qf.row + (blk << 3));
-            const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
+        bool live = true;       // false: the bins left lie behind the last post (a floor that ends below n)
+        auto flush = [&]() {
+            fits.set(seg, 0, xa); fits.set(seg, 1, ya); fits.set(seg, 2, x2a); fits.set(seg, 3, xya); fits.set(seg, 4, na);
+            fits.set(seg, 5, xb); fits.set(seg, 6, yb); fits.set(seg, 7, x2b); fits.set(seg, 8, xyb); fits.set(seg, 9, nb);
+            nonzero += na;
+            xa = ya = x2a = xya = na = xb = yb = x2b = xyb = nb = 0;
+        };
+        const int last = (n - 1) >> 3;      // (the row has b.n >= n entries, a multiple of 8)
+        for (int blk0 = 0; blk0 <= last && live; blk0 += 4) {
+            uint4 v4[4];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                i = (blk << 3) + u;
-                const int w = (int)((wd[u >> 1] >> ((u & 1) * 16)) & 0xffffu);
-                const int quantized = w & 0x7fff;
-                if ((unsigned)(i - x0) <= (unsigned)(x1 - x0) && quantized) {
-                    if (w & 0x8000) {
-                        xa += i; ya += quantized; x2a += i * i; xya += i * quantized; na++;
-                    } else {
-                        xb += i; yb += quantized; x2b += i * i; xyb += i * quantized; nb++;
+            for (int r = 0; r < 4; r++) v4[r] = *reinterpret_cast<const uint4 *>(qf.row + ((blk0 + r <= last ? blk0 + r : last) << 3));
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                if (blk0 + r > last || !live) continue;
+                const uint32_t wd[4] = {v4[r].x, v4[r].y, v4[r].z, v4[r].w};
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    i = ((blk0 + r) << 3) + u;
+                    const int w = (int)((wd[u >> 1] >> ((u & 1) * 16)) & 0xffffu);
+                    const int quantized = w & 0x7fff;
+                    if (quantized && live) {
+                        if (w & 0x8000) { xa += i; ya += quantized; x2a += i * i; xya += i * quantized; na++; }
+                        else { xb += i; yb += quantized; x2b += i * i; xyb += i * quantized; nb++; }
+                    }
+                    if (i == end) {
+                        flush();
+                        if (seg + 1 < nseg && look->sorted_index[seg + 1] == i) {
+                            seg++;      // the post's bin opens the next segment too
+                            const int e = look->sorted_index[seg + 1];
+                            end = e >= n ? n - 1 : e;
+                            if (quantized) {
+                                if (w & 0x8000) { xa += i; ya += quantized; x2a += i * i; xya += i * quantized; na++; }
+                                else { xb += i; yb += quantized; x2b += i * i; xyb += i * quantized; nb++; }
+                            }
+                        } else {
+                            live = false;   // the last segment (or one cut short at n - 1) is over
+                        }
                     }
                 }
             }
         }
-        fits.set(seg, 0, xa); fits.set(seg, 1, ya); fits.set(seg, 2, x2a); fits.set(seg, 3, xya); fits.set(seg, 4, na);
-        fits.set(seg, 5, xb); fits.set(seg, 6, yb); fits.set(seg, 7, x2b); fits.set(seg, 8, xyb); fits.set(seg, 9, nb);
-        nonzero += na;
     }
 
     if (!nonzero) {
@@ -323,25 +349,36 @@ __global__ void k_floor_fit(vbm_batch b, int lpw)
                             // y - val > floor(maxunder)  (thresholds >= 0): integer compares.  After a violation
                             // mse / cnt are never read (split = 1), so the group is simply abandoned.
                             const int xlo = lx + 1, xhi = hx - 1;
-                            for (int blk = xlo >> 3; blk <= xhi >> 3 && split < 0; blk++) {
-                                const uint4 v = *reinterpret_cast<const uint4 *>(qf.row + (blk << 3));
-                                const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
+                            // (four pieces are fetched before the first is looked at: a lane's loads would be a chain
+                            // of round trips otherwise; pieces past the range are fetched again from its last one)
+                            const int blast = xhi >> 3;
+                            for (int blk0 = xlo >> 3; blk0 <= blast && split < 0; blk0 += 4) {
+                                uint4 v4[4];
 #pragma unroll
-                                for (int u = 0; u < 8; u++) {
-                                    x = (blk << 3) + u;
-                                    if ((unsigned)(x - xlo) <= (unsigned)(xhi - xlo)) {
-                                        err = err + ady;
-                                        if (err >= adx) {
-                                            err -= adx;
-                                            y += sy;
-                                        } else {
-                                            y += base;
+                                for (int r = 0; r < 4; r++)
+                                    v4[r] = *reinterpret_cast<const uint4 *>(qf.row + ((blk0 + r <= blast ? blk0 + r : blast) << 3));
+#pragma unroll
+                                for (int r = 0; r < 4; r++) {
+                                    const int blk = blk0 + r;
+                                    if (blk > blast || split >= 0) continue;
+                                    const uint32_t wd[4] = {v4[r].x, v4[r].y, v4[r].z, v4[r].w};
+#pragma unroll
+                                    for (int u = 0; u < 8; u++) {
+                                        x = (blk << 3) + u;
+                                        if ((unsigned)(x - xlo) <= (unsigned)(xhi - xlo)) {
+                                            err = err + ady;
+                                            if (err >= adx) {
+                                                err -= adx;
+                                                y += sy;
+                                            } else {
+                                                y += base;
+                                            }
+                                            wv = (int)((wd[u >> 1] >> ((u & 1) * 16)) & 0xffffu);
+                                            val = wv & 0x7fff;
+                                            const int d = y - val;
+                                            mse += d * d;
+                                            if ((wv & 0x8000) && val && (-d > imaxover || d > imaxunder)) split = 1;
                                         }
-                                        wv = (int)((wd[u >> 1] >> ((u & 1) * 16)) & 0xffffu);
-                                        val = wv & 0x7fff;
-                                        const int d = y - val;
-                                        mse += d * d;
-                                        if ((wv & 0x8000) && val && (-d > imaxover || d > imaxunder)) split = 1;
                                     }
                                 }
                             }
@@ -422,361 +459,6 @@ __global__ void k_floor_fit(vbm_batch b, int lpw)
         }
     }
     b.post_valid[lane] = 1;
-}
-
-// ---------------------------------------------------------------------------------------------
-// floor1_fit with G lanes per channel-block (64 / G blocks per wavefront).  What is heavy in the fit are its loops
-// over bins — accumulate_fit walks all n of them, the inspect_error calls of the greedy splitting some thousands
-// more — and those are sums of integers and an "any bin violates" test: order free.  The G lanes of a block
-// split them (16-byte pieces of the block's qf row, a whole cache line per step of the group) and add up with
-// shuffles.  The decisions in between (which post next, split or not, the neighbour runs) are taken by all G lanes
-// alike on the block's small arrays in LDS; the least-squares sums of fit_line are double-precision chains in
-// segment order (lib/floor1.c:497-511) that every lane of the group adds up for itself from the per-segment
-// addends — those depend on the segment alone and are formed once.
-//
-// LDS per block: six int arrays of posts entries (neighbours, memo, the two fit values, the output) and
-// [segments][5] doubles — 4.2 KB.
-#define FITC_POSTS (VBM_VIF_POSIT + 3)
-struct fitc_block {
-    double terms[(VBM_VIF_POSIT + 1) * 5];      // first the ten int sums of accumulate_fit per segment (same 40 bytes)
-    int lo[FITC_POSTS], hi[FITC_POSTS], memo[FITC_POSTS], fa[FITC_POSTS], fb[FITC_POSTS], out[FITC_POSTS];
-};
-
-// fit_line (lib/floor1.c:477-535) from the per-segment addends
-__device__ __forceinline__ int fitc_line(const double *__restrict__ terms, const int *__restrict__ sorted_index, const int seg0,
-                                         const int fits, int *y0, int *y1)
-{
-    double xb = 0, yb = 0, x2b = 0, xyb = 0, bn = 0;
-    const int x0 = sorted_index[seg0];
-    const int x1 = sorted_index[seg0 + fits];
-    for (int i = seg0; i < seg0 + fits; i++) {
-        const double *t = terms + i * 5;
-        xb += t[0];
-        yb += t[1];
-        x2b += t[2];
-        xyb += t[3];
-        bn += t[4];
-    }
-    if (*y0 >= 0) {
-        xb += x0;
-        yb += *y0;
-        x2b += x0 * x0;
-        xyb += *y0 * x0;
-        bn++;
-    }
-    if (*y1 >= 0) {
-        xb += x1;
-        yb += *y1;
-        x2b += x1 * x1;
-        xyb += *y1 * x1;
-        bn++;
-    }
-    {
-        double denom = (bn * x2b - xb * xb);
-        if (denom > 0.) {
-            double aa = (yb * x2b - xyb * xb) / denom;
-            double bb = (bn * xyb - xb * yb) / denom;
-            *y0 = (int)rint(aa + bb * x0);
-            *y1 = (int)rint(aa + bb * x1);
-            if (*y0 > 1023) *y0 = 1023;
-            if (*y1 > 1023) *y1 = 1023;
-            if (*y0 < 0) *y0 = 0;
-            if (*y1 < 0) *y1 = 0;
-            return 0;
-        } else {
-            *y0 = 0;
-            *y1 = 0;
-            return 1;
-        }
-    }
-}
-
-__device__ __forceinline__ int fitc_post_Y(const int *A, const int *B, int pos)
-{
-    const int a = A[pos], bb = B[pos];
-    if (a < 0) return bb;
-    if (bb < 0) return a;
-    return (a + bb) >> 1;
-}
-
-template <int G>
-__device__ __forceinline__ int group_sum(int v)
-{
-#pragma unroll
-    for (int m = G >> 1; m > 0; m >>= 1) v += __shfl_xor(v, m, G);
-    return v;
-}
-
-template <int G>
-__global__ __launch_bounds__(64) void k_floor_fit_coop(vbm_batch b)
-{
-    constexpr int BPW = 64 / G;
-    __shared__ __align__(16) fitc_block sm[BPW];
-    const int tid = (int)threadIdx.x, grp = tid / G, g = tid - grp * G;
-    const int lane = (int)blockIdx.x * BPW + grp;      // the channel-block of this group
-    if (lane >= vbm_ncb(b)) return;
-    const size_t tb = (size_t)(lane >> 6) * b.slab_words + (lane & 63);
-    const uint16_t *__restrict__ row = b.qf_bm + (size_t)lane * b.n;   // rows are 16-byte aligned: n is a multiple of 8
-    const vbm_setup *s = b.setup;
-    const vbm_map *map = &s->map[b.W];
-    const vbm_floor *look = &s->floor[map->floorsubmap[map->chmuxlist[lane % b.ch]]];
-    const int n = look->n;
-    const int posts = look->posts;
-    const int nseg = posts - 1;
-    const float maxover = look->maxover, maxunder = look->maxunder, maxerr = look->maxerr;
-    const float twofitweight = look->twofitweight;
-    const int imaxover = (int)floorf(maxover), imaxunder = (int)floorf(maxunder);   // both >= 0 in every floor template
-    const int *__restrict__ sorted_index = look->sorted_index, *__restrict__ reverse_index = look->reverse_index;
-    const int *__restrict__ postlist = look->postlist;
-    fitc_block &B = sm[grp];
-    int *sums = reinterpret_cast<int *>(B.terms);       // [segment][10]: xa ya x2a xya an xb yb x2b xyb bn
-
-    for (int j = g; j < nseg * 10; j += G) sums[j] = 0;
-    for (int j = g; j < posts; j += G) {
-        B.fa[j] = -200; B.fb[j] = -200; B.lo[j] = 0; B.hi[j] = 1; B.memo[j] = -1;
-    }
-    __builtin_amdgcn_wave_barrier();
-
-    // ---- accumulate_fit over every minimal division (lib/floor1.c:427-475, :625-628).  A segment takes the bins
-    //      sorted_index[seg] .. min(sorted_index[seg + 1], n - 1), both ends included: a post's own bin counts for
-    //      the segment on either side.  A lane walks its 8-bin pieces with the segment's ten sums in registers and
-    //      hands them to LDS (integer atomics) when it leaves the segment.
-    {
-        int seg = 0, end = sorted_index[1] >= n ? n - 1 : sorted_index[1];
-        int xa = 0, ya = 0, x2a = 0, xya = 0, na = 0, xb = 0, yb = 0, x2b = 0, xyb = 0, nb = 0;
-        auto flush = [&]() {
-            int *q = sums + seg * 10;
-            if (na) { atomicAdd(q + 0, xa); atomicAdd(q + 1, ya); atomicAdd(q + 2, x2a); atomicAdd(q + 3, xya); atomicAdd(q + 4, na); }
-            if (nb) { atomicAdd(q + 5, xb); atomicAdd(q + 6, yb); atomicAdd(q + 7, x2b); atomicAdd(q + 8, xyb); atomicAdd(q + 9, nb); }
-            xa = ya = x2a = xya = na = xb = yb = x2b = xyb = nb = 0;
-        };
-        bool live = true;       // false: the bins left lie behind the last post (a floor that ends below n)
-        auto next_seg = [&]() {
-            if (seg + 1 >= nseg) { live = false; end = 0x7fffffff; return; }
-            seg++;
-            const int e = sorted_index[seg + 1];
-            end = e >= n ? n - 1 : e;
-        };
-        for (int blk = g; blk <= ((n - 1) >> 3); blk += G) {       // (the row has b.n >= n entries, a multiple of 8)
-            const uint4 v = *reinterpret_cast<const uint4 *>(row + (blk << 3));
-            const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
-            if ((blk << 3) > end) {
-                flush();
-                while ((blk << 3) > end) next_seg();
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int i = (blk << 3) + u;
-                const int w = (int)((wd[u >> 1] >> ((u & 1) * 16)) & 0xffffu);
-                const int quantized = w & 0x7fff;
-                if (quantized && live) {
-                    if (w & 0x8000) { xa += i; ya += quantized; x2a += i * i; xya += i * quantized; na++; }
-                    else { xb += i; yb += quantized; x2b += i * i; xyb += i * quantized; nb++; }
-                }
-                if (i == end) {
-                    flush();
-                    if (seg + 1 < nseg && sorted_index[seg + 1] == i) {     // (not a segment cut short at n - 1: the ones behind it are empty)
-                        next_seg();     // the post's bin opens the next segment too
-                        if (quantized) {
-                            if (w & 0x8000) { xa += i; ya += quantized; x2a += i * i; xya += i * quantized; na++; }
-                            else { xb += i; yb += quantized; x2b += i * i; xyb += i * quantized; nb++; }
-                        }
-                    } else {
-                        live = false;   // the last segment (or one cut short at n - 1) is over
-                        end = 0x7fffffff;
-                    }
-                }
-            }
-        }
-        flush();
-    }
-    __builtin_amdgcn_wave_barrier();
-
-    // ---- nothing above the floor's reach: no posts (lib/floor1.c:630)
-    {
-        int nz = 0;
-        for (int j = g; j < nseg; j += G) nz += sums[j * 10 + 4];
-        nz = group_sum<G>(nz);
-        if (!nz) {
-            if (g == 0) b.post_valid[lane] = 0;
-            return;
-        }
-    }
-
-    // ---- the addends of fit_line per segment (lib/floor1.c:497-511): they depend on the segment's sums alone
-    for (int j = g; j < nseg; j += G) {
-        const int *q = sums + j * 10;
-        const int axa = q[0], aya = q[1], ax2a = q[2], axya = q[3], aan = q[4];
-        const int axb = q[5], ayb = q[6], ax2b = q[7], axyb = q[8], abn = q[9];
-        const double weight = (double)((float)(abn + aan) * twofitweight / (float)(aan + 1)) + 1.;
-        const double t0 = axb + axa * weight, t1 = ayb + aya * weight, t2 = ax2b + ax2a * weight, t3 = axyb + axya * weight,
-                     t4 = abn + aan * weight;
-        double *t = B.terms + j * 5;
-        t[0] = t0; t[1] = t1; t[2] = t2; t[3] = t3; t[4] = t4;
-    }
-    __builtin_amdgcn_wave_barrier();
-
-    // ---- greedy splitting (lib/floor1.c:632-719): every lane of the group takes the same decisions
-    {
-        int y0 = -200, y1 = -200;
-        fitc_line(B.terms, sorted_index, 0, posts - 1, &y0, &y1);
-        if (g == 0) { B.fa[0] = y0; B.fb[0] = y0; B.fb[1] = y1; B.fa[1] = y1; }
-        __builtin_amdgcn_wave_barrier();
-
-        for (int i = 2; i < posts; i++) {
-            const int sortpos = reverse_index[i];
-            const int ln = B.lo[sortpos];
-            const int hn = B.hi[sortpos];
-            if (B.memo[ln] == hn) continue;
-            const int lsortpos = reverse_index[ln];
-            const int hsortpos = reverse_index[hn];
-            __builtin_amdgcn_wave_barrier();
-            if (g == 0) B.memo[ln] = hn;
-            const int lx = postlist[ln];
-            const int hx = postlist[hn];
-            const int ly = fitc_post_Y(B.fa, B.fb, ln);
-            const int hy = fitc_post_Y(B.fa, B.fb, hn);
-
-            // inspect_error (lib/floor1.c:537-586): the line's value at bin lx + k is ly + k base + (wraps of the
-            // error term: floor(k ady / adx)) steps of sy - base — a lane starts its piece from there
-            int split = -1;
-            {
-                const int dy = hy - ly;
-                const int adx = hx - lx;
-                int ady = abs(dy);
-                const int base = dy / adx;
-                const int sgn = dy < 0 ? -1 : 1;
-                ady -= abs(base * adx);
-                int mse, cnt = 1;
-                {
-                    const int wv = row[lx];
-                    const int val = wv & 0x7fff;
-                    mse = (ly - val);
-                    mse *= mse;
-                    if (wv & 0x8000) {
-                        if (ly + maxover < val) split = 1;
-                        if (ly - maxunder > val) split = 1;
-                    }
-                }
-                if (split < 0 && lx + 1 < hx) {
-                    const int xlo = lx + 1, xhi = hx - 1;
-                    int part = 0, viol = 0;
-                    for (int blk = (xlo >> 3) + g; blk <= xhi >> 3; blk += G) {
-                        const uint4 v = *reinterpret_cast<const uint4 *>(row + (blk << 3));
-                        const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
-                        const int xf = (blk << 3) > xlo ? (blk << 3) : xlo;     // first bin of the piece inside the range
-                        const int a = (xf - 1 - lx) * ady;                      // state after the bins before it
-                        const int wraps = a / adx;
-                        int err = a - wraps * adx;
-                        int y = ly + (xf - 1 - lx) * base + wraps * sgn;
-#pragma unroll
-                        for (int u = 0; u < 8; u++) {
-                            const int x = (blk << 3) + u;
-                            if ((unsigned)(x - xlo) <= (unsigned)(xhi - xlo)) {
-                                err += ady;
-                                if (err >= adx) {
-                                    err -= adx;
-                                    y += base + sgn;
-                                } else {
-                                    y += base;
-                                }
-                                const int wv = (int)((wd[u >> 1] >> ((u & 1) * 16)) & 0xffffu);
-                                const int val = wv & 0x7fff;
-                                const int d = y - val;
-                                part += d * d;
-                                if ((wv & 0x8000) && val && (-d > imaxover || d > imaxunder)) viol = 1;
-                            }
-                        }
-                    }
-                    mse += group_sum<G>(part);
-                    if (group_sum<G>(viol)) split = 1;
-                    cnt += xhi - xlo + 1;
-                }
-                if (split < 0) {
-                    if (maxover * maxover / cnt > maxerr) split = 0;
-                    else if (maxunder * maxunder / cnt > maxerr) split = 0;
-                    else if (mse / cnt > maxerr) split = 1;
-                    else split = 0;
-                }
-            }
-
-            if (split) {
-                int ly0 = -200, ly1 = -200, hy0 = -200, hy1 = -200;
-                const int ret0 = fitc_line(B.terms, sorted_index, lsortpos, sortpos - lsortpos, &ly0, &ly1);
-                const int ret1 = fitc_line(B.terms, sorted_index, sortpos, hsortpos - sortpos, &hy0, &hy1);
-                if (ret0) {
-                    ly0 = ly;
-                    ly1 = hy0;
-                }
-                if (ret1) {
-                    hy0 = ly1;
-                    hy1 = hy;
-                }
-                __builtin_amdgcn_wave_barrier();
-                if (ret0 && ret1) {
-                    if (g == 0) { B.fa[i] = -200; B.fb[i] = -200; }
-                } else {
-                    if (g == 0) {
-                        B.fb[ln] = ly0;
-                        if (ln == 0) B.fa[ln] = ly0;
-                        B.fa[i] = ly1;
-                        B.fb[i] = hy0;
-                        B.fa[hn] = hy1;
-                        if (hn == 1) B.fb[hn] = hy1;
-                    }
-                    if (ly1 >= 0 || hy0 >= 0) {
-                        // the run of sort positions below sortpos whose upper neighbour is hn, and the run above whose
-                        // lower neighbour is ln, now have post i there: G positions per look
-                        for (int j0 = sortpos - 1; j0 >= 0; j0 -= G) {
-                            const int j = j0 - g;
-                            const bool hit = j >= 0 && B.hi[j] == hn;
-                            const unsigned m = (unsigned)(__ballot(hit) >> (grp * G)) & ((1u << G) - 1u);
-                            const int run = __builtin_ctz(~m);        // leading lanes (g = 0, 1, ...) that still match
-                            if (g < run) B.hi[j] = i;
-                            if (run < G) break;
-                        }
-                        for (int j0 = sortpos + 1; j0 < posts; j0 += G) {
-                            const int j = j0 + g;
-                            const bool hit = j < posts && B.lo[j] == ln;
-                            const unsigned m = (unsigned)(__ballot(hit) >> (grp * G)) & ((1u << G) - 1u);
-                            const int run = __builtin_ctz(~m);
-                            if (g < run) B.lo[j] = i;
-                            if (run < G) break;
-                        }
-                    }
-                }
-            } else {
-                __builtin_amdgcn_wave_barrier();
-                if (g == 0) { B.fa[i] = -200; B.fb[i] = -200; }
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-
-        // ---- the posts as floor1_encode wants them (lib/floor1.c:721-747): predicted posts carry bit 15
-        {
-            const int o0 = fitc_post_Y(B.fa, B.fb, 0), o1 = fitc_post_Y(B.fa, B.fb, 1);
-            __builtin_amdgcn_wave_barrier();
-            if (g == 0) { B.out[0] = o0; B.out[1] = o1; }
-            __builtin_amdgcn_wave_barrier();
-            for (int i = 2; i < posts; i++) {
-                const int ln = look->loneighbor[i - 2];
-                const int hn = look->hineighbor[i - 2];
-                const int x0 = postlist[ln];
-                const int x1 = postlist[hn];
-                const int py0 = B.out[ln];
-                const int py1 = B.out[hn];
-                const int predicted = render_point(x0, x1, py0, py1, postlist[i]);
-                const int vx = fitc_post_Y(B.fa, B.fb, i);
-                const int o = (vx >= 0 && predicted != vx) ? vx : (predicted | 0x8000);
-                __builtin_amdgcn_wave_barrier();
-                if (g == 0) B.out[i] = o;
-                __builtin_amdgcn_wave_barrier();
-            }
-            int *output = b.postT;
-            for (int j = g; j < posts; j += G) T(output, j) = B.out[j];
-        }
-    }
-    if (g == 0) b.post_valid[lane] = 1;
 }
 
 // floor1_interpolate_fit for the blobs between the three fitted ones (lib/mapping0.c:1169-1181,
@@ -976,16 +658,10 @@ extern "C" int vbm_launch_floor_fit(const vbm_batch *b, hipStream_t st)
     // (fit alone 0.59 -> 0.35 ms).  Not for a full batch: 70 KB per wavefront on every CU keeps the LDS-staged
     // kernels of the other half of the pipeline (MDCT, couple, residue VQ) off the chip while the fit runs —
     // measured 3.91 ms per step against 3.76 (VBM_FLOORFIT_LDS=1 forces it, VBM_FLOORFIT_PRIVATE=1 forbids it).
-    static int coop = -1;
-    if (coop < 0) coop = getenv("VBM_FLOORFIT_COOP") ? atoi(getenv("VBM_FLOORFIT_COOP")) : 8;
-    if (coop == 8 || coop == 16 || coop == 4) {
-        const int bpw = 64 / coop;
-        const dim3 grid((unsigned)((b->ncb + bpw - 1) / bpw));
-        if (coop == 8) hipLaunchKernelGGL(k_floor_fit_coop<8>, grid, dim3(64), 0, st, *b);
-        else if (coop == 16) hipLaunchKernelGGL(k_floor_fit_coop<16>, grid, dim3(64), 0, st, *b);
-        else hipLaunchKernelGGL(k_floor_fit_coop<4>, grid, dim3(64), 0, st, *b);
-        return hipGetLastError() == hipSuccess ? 0 : -2;
-    }
+    // (A variant with 8 / 16 / 32 lanes per block — bin loops split over the lanes, row, addends and fit state in
+    // LDS — was built and measured in round 2: 0.48 ms alone against 0.58, but 3.3 ms per step against 2.87 in the
+    // pipeline, where its 18 KB of LDS per wavefront keep the other half's kernels off the CUs; the per-block chain
+    // of ~27 greedy steps, each a handful of dependent reads and a double-precision solve, is what bounds either.)
     size_t lds = (size_t)(b->fit_max_posts - 1) * 10 * 64 * sizeof(int);
     static int force = -1;
     if (force < 0) force = getenv("VBM_FLOORFIT_LDS") ? 1 : 0;
