@@ -487,6 +487,297 @@ __global__ void k_mix(vbm_batch b, int nchunks)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// _vp_offset_and_mix for impulse blocks (block_mode 0, n = 128 / 256) with aoTuV M3 (lib/psy.c:4148-4272 set_m3p,
+// :4330-4400 M3 MAIN): ONE wavefront per channel-block, a lane per bin (n / 64 bins each).  Read bin by bin the
+// function looks serial — M3's set-up walks tempmdct with read-modify-writes, the main loop reads and rewrites it
+// and keeps npeak up to date per partition — but:
+//   * the set-up loop (for i, for j < bfn[i]: tempmdct[i + j] conditionally += 5 / bfn[i + j]) touches entry k = i + j
+//     only, so entry k is its own chain over i = k - j in rising order: lane k walks it alone;
+//   * the main loop reads and writes tempmdct[i] of its own bin only;
+//   * the npeak updates of a partition (a tone-like bin sets -1, another qualifying bin clears a positive value) end
+//     in a value that does not depend on their order: -1 if any bin was tone-like, else min(value, 0) if any bin
+//     qualified.
+// Every input row is read once (all of a lane's loads in flight together), every output written once.
+template <int SEL, bool MANAGED>
+__global__ __launch_bounds__(64) void k_mix_impulse(vbm_batch b)
+{
+    constexpr bool BUF = (!MANAGED || SEL == 2);   // mp->mdctbuf_flag of set_m3p when the rate is high (lib/psy.c:4165-4173)
+    constexpr int RMAX = 4;                         // n <= 256
+    __shared__ float s_lm[256];
+    __shared__ int s_bfn[256];
+    __shared__ int s_tone[64], s_qual[64];          // per partition (n / partition <= 64)
+    const int lane = (int)blockIdx.x;               // channel-block
+    const int t = (int)threadIdx.x;
+    if (lane >= vbm_ncb(b)) return;
+    if (MANAGED && SEL != 1 && !b.post_valid_blob[(size_t)(VBM_PACKETBLOBS / 2) * b.L + lane]) return;
+    const size_t tb = TB(b, lane);
+    const vbm_setup *s = b.setup;
+    const vbm_psy *p = psy_of(b);
+    const int n = p->n;
+    const int R = n >> 6;
+    const int sb = lane / b.ch, c = lane - sb * b.ch;
+    const int sid = b.stream_id[sb];
+    const int col = sid * b.ch + c;
+    float *lastmdct = b.st.mblock + (size_t)(col >> 6) * b.st.slab_words + (col & 63);   // element i at [i*64]
+    float *tempmdct = b.st.tblock + (size_t)(col >> 6) * b.st.slab_words + (col & 63);
+    const float *noise = b.noiseT, *tone = b.toneT;
+    float *logmask = b.logmaskT, *mdct = b.mdctT, *logmdct = b.logmdctT, *npeak = b.npeakT;
+    const int nW_modenumber = (b.wflags[sb] >> 1) & 1;
+    const int lW_block_mode = b.st.lW_block_mode[sid];
+    const int lW_no = b.st.lW_no[sid];
+    const int impadnum = b.st.impadnum[sid];
+    float low_compand = b.st.lowcomp[col];
+    const int end_block = s->floor[b.W].info_n;   // vif->n, lib/mapping0.c:1055
+    const int hsrate = ((p->rate < 26000) ? 0 : 1);
+    const int partition = (p->normal_p ? p->normal_partition : 16);
+    const float toneatt = p->tone_masteratt[SEL];
+
+    // ---- inputs of the lane's bins
+    float nz[RMAX], tn[RMAX], lm[RMAX], md[RMAX], last[RMAX], temp[RMAX];
+#pragma unroll
+    for (int r = 0; r < RMAX; r++) {
+        const int i = t + 64 * r;
+        nz[r] = tn[r] = lm[r] = md[r] = last[r] = temp[r] = 0.f;
+        if (r < R) {
+            nz[r] = T(noise, i);
+            tn[r] = T(tone, i);
+            lm[r] = T(logmdct, i);
+            if (SEL == 1) md[r] = T(mdct, i);
+            last[r] = lastmdct[(size_t)i * 64];
+            temp[r] = tempmdct[(size_t)i * 64];
+        }
+    }
+    {
+        const int *g = (n == 128) ? s->freq_bfn128 : s->freq_bfn256;
+        for (int i = t; i < n; i += 64) s_bfn[i] = g[i];
+    }
+#pragma unroll
+    for (int r = 0; r < RMAX; r++)
+        if (r < R) s_lm[t + 64 * r] = lm[r];
+    s_tone[t] = 0; s_qual[t] = 0;
+
+    mod3 mp3;
+    mp3.sw = 0; mp3.mdctbuf_flag = 0; mp3.noise_rate = mp3.noise_rate_low = mp3.noise_center = mp3.tone_rate = 0.f;
+    int m4_start = p->normal_start;
+    int m4_end = p->tonecomp_endp;
+    const float m4_thres = p->tonecomp_thres;
+    int m4_end_block = end_block;
+    if (low_compand < 0 || (double)toneatt < 25.) low_compand = 0;
+    else low_compand = (float)((double)low_compand * ((double)toneatt - 25.));
+
+    // set_m3p (lib/psy.c:4148-4272), block_mode 0
+    float sub = 0.f;
+    double add = 0.;
+    if (hsrate) {
+        mp3.mdctbuf_flag = BUF ? 1 : 0;
+        if (!(MANAGED && SEL == 0)) {
+            int count;
+            if (n == 128) {
+                if (toneatt < 3) count = 2;
+                else count = 3;
+                if (!lW_block_mode) {
+                    if (lW_no < 8) {
+                        mp3.noise_rate = (float)(0.7 - (double)((float)(lW_no - 1) / 17));
+                        mp3.noise_center = (float)(lW_no * count);
+                        mp3.tone_rate = 8 - lW_no;
+                    } else {
+                        mp3.noise_rate = (float)0.3;
+                        mp3.noise_center = 25;
+                        mp3.tone_rate = 0;
+                        if ((lW_no * count) < 24) mp3.noise_center = lW_no * count;
+                    }
+                } else {
+                    mp3.noise_rate = (float)0.7;
+                    mp3.noise_center = 0;
+                    mp3.tone_rate = 8.f;
+                }
+                mp3.noise_rate_low = 0;
+                mp3.sw = 1;
+                if (impadnum) mp3.noise_rate = (float)((double)mp3.noise_rate * (impadnum * 0.125));
+                sub = 5; add = 5.;
+            } else {
+                if (!lW_block_mode) {
+                    count = 6;
+                    if (lW_no < 4) {
+                        mp3.noise_rate = (float)(0.4 - (double)((float)(lW_no - 1) / 11));
+                        mp3.noise_center = (float)(lW_no * count + 12);
+                        mp3.tone_rate = 8 - lW_no * 2;
+                    } else {
+                        mp3.noise_rate = (float)0.2;
+                        mp3.noise_center = 30;
+                        mp3.tone_rate = 0;
+                    }
+                } else {
+                    mp3.noise_rate = (float)0.6;
+                    mp3.noise_center = 12;
+                    mp3.tone_rate = 8.f;
+                }
+                mp3.noise_rate_low = 0;
+                mp3.sw = 1;
+                if (impadnum) mp3.noise_rate = (float)((double)mp3.noise_rate * (impadnum * 0.0625));
+                sub = 10; add = 10.;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- M3 set-up of tempmdct (lib/psy.c:4199-4215 / :4246-4262)
+    if (mp3.sw && BUF) {
+        int bmax = 0;
+        for (int i = t; i < n; i += 64) bmax = max(bmax, s_bfn[i]);
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) bmax = max(bmax, __shfl_xor(bmax, m));
+#pragma unroll
+        for (int r = 0; r < RMAX; r++) {
+            if (r >= R) continue;
+            const int k = t + 64 * r;
+            float tv = lW_block_mode ? last[r] - sub : temp[r] - sub;
+            const double ck = add / (double)(float)s_bfn[k];
+            for (int i = (k - bmax + 1 > 0 ? k - bmax + 1 : 0); i < k; i++) {
+                const int bf = s_bfn[i];
+                const int j = k - i;
+                if (j < bf) {
+                    const float cell = 75 / (float)bf;
+                    const float freqbuf = s_lm[i] - (cell * j);
+                    if (tv < freqbuf) tv = (float)((double)tv + ck);
+                }
+            }
+            temp[r] = tv;
+        }
+    }
+
+    // M4 PRE
+    m4_end_block += p->normal_partition;
+    if (m4_end_block > n) m4_end_block = n;
+    if (!hsrate) {
+        m4_end = m4_end_block;
+    } else {
+        if (p->normal_thresh > 1.) m4_start = 9999;
+    }
+    const float *__restrict__ noiseoffset = p->noiseoffset[SEL];
+    const float noisemaxsupp = p->noisemaxsupp, m_val = p->m_val;
+    const int tonecomp_endp = p->tonecomp_endp, m3n0 = p->m3n[0], m3n1 = p->m3n[1], m3n2 = p->m3n[2];
+
+    float lmv[RMAX], mdo[RMAX];
+#pragma unroll
+    for (int r = 0; r < RMAX; r++) {
+        lmv[r] = 0.f; mdo[r] = md[r];
+        if (r >= R) continue;
+        const int i = t + 64 * r;
+        float val = nz[r] + noiseoffset[i];
+        float tval = tn[r] + toneatt;
+        const float l = lm[r];
+        if (i <= m4_start) tval -= low_compand;
+        if (val > noisemaxsupp) val = noisemaxsupp;
+
+        // M3 MAIN
+        if (mp3.sw) {
+            if (val > tval) {
+                const float lst = last[r];
+                if ((val > lst) && (l > (temp[r] + mp3.noise_center))) {
+                    int toneac = 0;
+                    float valmask = 0;
+                    float rate_mod;
+                    float mainth;
+
+                    if (mp3.mdctbuf_flag == 1) temp[r] = l;
+                    if (l > lst) rate_mod = mp3.noise_rate;
+                    else rate_mod = mp3.noise_rate_low;
+                    if (!impadnum && (i < tonecomp_endp) && ((val - lst) > 20.f)) {
+                        float dBsub = (l - lst);
+                        if (dBsub > 25.f) {
+                            toneac = 1;
+                            if (tval > -100.f && ((l - tval) < 48.f)) {
+                                float tr_cur = mp3.tone_rate;
+                                if (dBsub < 35.f) tr_cur *= ((35.f - dBsub) * .1f);
+                                tval -= tr_cur;
+                                if (tval < -100.f) tval = -100.f;
+                                if ((l - tval) > 48.f) tval = l - 48.f;
+                            }
+                        }
+                    }
+                    if (i > m3n0) {
+                        mainth = 30.f;
+                    } else if (i > m3n1) {
+                        mainth = 20.f;
+                    } else if (i > m3n2) {
+                        mainth = 10.f;
+                        rate_mod *= .5f;
+                    } else {
+                        mainth = 10.f;
+                        rate_mod *= .3f;
+                    }
+                    if ((val - tval) > mainth) valmask = ((val - tval - mainth) * .1f + mainth) * rate_mod;
+                    else valmask = (val - tval) * rate_mod;
+
+                    if ((val - valmask) > lst) val -= valmask;
+                    else val = lst;
+
+                    if (toneac) {
+                        float tmp = val - VMAX(lst, -140);
+                        if (tmp > 20.f) val -= (tmp - 20.f) * .2f;
+                    }
+                    // npeak of the bin's partition: see the header
+                    if (toneac == 1) atomicOr(&s_tone[i / partition], 1);
+                    else atomicOr(&s_qual[i / partition], 1);
+                }
+            }
+        }
+
+        // M4 MAIN
+        float o;
+        if (val > tval) {
+            o = val;
+        } else if ((i > m4_start) && (i < m4_end)) {
+            if (l < tval) {
+                if (l < val) tval -= (tval - val) * m4_thres;
+                else tval = l;
+            }
+            o = tval;
+        } else
+            o = tval;
+        lmv[r] = o;
+
+        // M1 (offset_select == 1)
+        if (SEL == 1) {
+            const float m1_coeffi = (float)-17.2;
+            float m1_de;
+            val = val - l;
+            if (val > m1_coeffi) {
+                m1_de = (float)(1.0 - ((double)(val - m1_coeffi) * 0.005 * (double)m_val));
+                if (m1_de < 0) m1_de = (float)0.0001;
+            } else
+                m1_de = (float)(1.0 - ((double)(val - m1_coeffi) * 0.0003 * (double)m_val));
+            mdo[r] = md[r] * m1_de;
+        }
+    }
+    __syncthreads();     // every read of lastmdct / tempmdct / npeak above is done
+
+    // ---- outputs
+#pragma unroll
+    for (int r = 0; r < RMAX; r++) {
+        if (r >= R) continue;
+        const int i = t + 64 * r;
+        T(logmask, i) = lmv[r];
+        if (SEL == 1) T(mdct, i) = mdo[r];
+        if (mp3.sw && BUF) tempmdct[(size_t)i * 64] = temp[r];
+        // M3 SET lastmdct (lib/psy.c:4463-4475): a short block followed by a long one spreads every bin over eight
+        if (mp3.mdctbuf_flag == 1) {
+            if (nW_modenumber) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) lastmdct[(size_t)(i * 8 + j) * 64] = lm[r];
+            } else {
+                lastmdct[(size_t)i * 64] = lm[r];
+            }
+        }
+    }
+    if (mp3.sw && t < (n + partition - 1) / partition) {
+        if (s_tone[t]) T(npeak, t) = -1.f;
+        else if (s_qual[t] && T(npeak, t) > 0) T(npeak, t) = 0;
+    }
+}
+
 }  // namespace
 
 static inline dim3 grid_for(int lanes) { return dim3((unsigned)((lanes + 63) / 64)); }
@@ -539,7 +830,9 @@ extern "C" int vbm_launch_mix(const vbm_batch *b, hipStream_t st)
 {
     const int nchunks = (b->block_mode == 0) ? 1 : bin_chunks(b);
     const dim3 grid((unsigned)((b->ncb + 63) / 64), (unsigned)nchunks);
-    if (b->block_mode == 0) {
+    if (b->block_mode == 0 && (b->n == 128 || b->n == 256))
+        hipLaunchKernelGGL((k_mix_impulse<1, false>), dim3((unsigned)b->ncb), dim3(64), 0, st, *b);
+    else if (b->block_mode == 0) {
         mix_m0_setup();
         hipLaunchKernelGGL((k_mix<1, false, false, true>), grid, dim3(64), kMixTempBytes, st, *b, nchunks);
     }
@@ -557,7 +850,12 @@ extern "C" int vbm_launch_mix_managed(const vbm_batch *b, int offset_select, hip
 {
     const int nchunks = (b->block_mode == 0) ? 1 : bin_chunks(b);
     const dim3 grid((unsigned)((b->ncb + 63) / 64), (unsigned)nchunks);
-    if (b->block_mode == 0) {
+    if (b->block_mode == 0 && (b->n == 128 || b->n == 256)) {
+        const dim3 g1((unsigned)b->ncb);
+        if (offset_select == 1) hipLaunchKernelGGL((k_mix_impulse<1, true>), g1, dim3(64), 0, st, *b);
+        else if (offset_select == 2) hipLaunchKernelGGL((k_mix_impulse<2, true>), g1, dim3(64), 0, st, *b);
+        else hipLaunchKernelGGL((k_mix_impulse<0, true>), g1, dim3(64), 0, st, *b);
+    } else if (b->block_mode == 0) {
         mix_m0_setup();
         if (offset_select == 1) hipLaunchKernelGGL((k_mix<1, true, false, true>), grid, dim3(64), kMixTempBytes, st, *b, nchunks);
         else if (offset_select == 2) hipLaunchKernelGGL((k_mix<2, true, false, true>), grid, dim3(64), kMixTempBytes, st, *b, nchunks);
