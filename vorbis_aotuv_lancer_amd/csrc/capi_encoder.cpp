@@ -1215,6 +1215,7 @@ static int run_group(vbm_encoder *e, vbm_encoder::round_graph &g, hipStream_t or
 // through the transition batches.  A job waits for the newest state event of every type it may follow, as they stood
 // before the round's own jobs went in; for the long types that includes the front half of the newest big batch (the
 // call's own in its later rounds: a stream that has fallen behind delivers a long block in every round).
+extern "C" void vbm_debug_stamp(hipStream_t st, int tag);   // util_kernels.hip (timing experiments)
 static int device_round_run_graphs(vbm_encoder *e, int w, const int *lane0, const int *cap, const float *d_blocks,
                                    uint8_t *d_packets, int *d_packet_bytes, bool first_round, hipStream_t fork)
 {
@@ -1256,11 +1257,15 @@ static int device_round_run_graphs(vbm_encoder *e, int w, const int *lane0, cons
         if ((err = hipStreamWaitEvent(qF, e->ev_fork, 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
         if ((rc = wait_preds(qF, 3, 4))) return rc;
         type_job jf = job_of(3, 1), jb = job_of(3, 2);
+        vbm_debug_stamp(qF, 10);
         if ((rc = run_group(e, e->gJ[w][3][1], qF, &jf, 1, 1))) return rc;
+        vbm_debug_stamp(qF, 11);
         if ((err = hipEventRecord(e->ev_state_big[w], qF)) != hipSuccess ||
             (err = hipStreamWaitEvent(qB, e->ev_state_big[w], 0)) != hipSuccess) return vbm_set_hip_error(err, "big batch hand-over");
+        vbm_debug_stamp(qB, 12);
         if ((rc = run_group(e, e->gJ[w][3][2], qB, &jb, 1, 2))) return rc;
         if ((rc = copy_outputs(e, jb, qB))) return rc;
+        vbm_debug_stamp(qB, 13);
         if ((err = hipEventRecord(e->ev_done[w][3], qB)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
         e->done_pending[w][3] = true;
         e->reuse_pending[w][3] = true;
@@ -1277,10 +1282,12 @@ static int device_round_run_graphs(vbm_encoder *e, int w, const int *lane0, cons
         // the next call waits for)
         type_job j = job_of(m, 1), j2 = job_of(m, 2);
         j.few = j2.few = 1;
+        vbm_debug_stamp(q, 20 + m);
         if ((rc = run_group(e, e->gJ[w][m][1], q, &j, 1, 0))) return rc;
         if ((err = hipEventRecord(e->ev_state[w][m], q)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
         if ((rc = run_group(e, e->gJ[w][m][2], q, &j2, 1, 0))) return rc;
         if ((rc = copy_outputs(e, j2, q))) return rc;
+        vbm_debug_stamp(q, 30 + m);
         if ((err = hipEventRecord(e->ev_done[w][m], q)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
         e->done_pending[w][m] = true;
         e->reuse_pending[w][m] = true;

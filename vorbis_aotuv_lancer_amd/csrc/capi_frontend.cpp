@@ -14,6 +14,7 @@
 #include "setup_host.h"
 #include "frontend.h"
 #include "frontend_kernels.h"
+extern "C" void vbm_debug_stamp(hipStream_t st, int tag);   // util_kernels.hip (timing experiments)
 #include "mdct_kernel.h"
 #include "kernels.h"
 #include "vbm_internal.h"
@@ -281,6 +282,7 @@ extern "C" int vbm_frontend_write(vbm_frontend *fe, const float *d_pcm, int vals
         int rc = fe_enter(fe, stream);
         if (rc) return rc;
     }
+    vbm_debug_stamp(st, 0);
     if (vbm_fe_launch_append(&fe->f, d_pcm, vals, s->pre_amplitude, st)) return VBM_EHIP;
     {   // the caller's buffer is free again once the append has run
         int rc = fe_leave(fe, stream);
@@ -699,6 +701,7 @@ extern "C" int vbm_frontend_encode_rounds_device(vbm_frontend *fe, int nrounds, 
     hipError_t err;
     int rc = fe_enter(fe, stream);
     if (rc) return rc;
+    vbm_debug_stamp(q, 1);
     if (!fe->lanes) {
         lane_layout(s, S, fe->lane0, fe->lane_cap, &fe->lanes);
         const size_t L = (size_t)fe->lanes;
@@ -760,11 +763,13 @@ extern "C" int vbm_frontend_encode_rounds_device(vbm_frontend *fe, int nrounds, 
                                      blocks + (size_t)fe->lane0[m] * ch * bs1, counts_ws + m, q))
                 return VBM_EHIP;
         }
+        vbm_debug_stamp(q, 2 + (r ? 1 : 0));
         rc = vbm_encoder_device_round_run(fe->enc, w, fe->lane0, fe->lane_cap, counts_ws, blocks,
                                           d_packets ? d_packets + (size_t)r * fe->lanes * maxb : nullptr, bytes_r, r == 0, q);
         if (rc) return rc;
         if (vbm_fe_launch_shift(&fe->f, fe->d_dec, q)) return VBM_EHIP;
     }
+    vbm_debug_stamp(q, 4);
     fe->mirrors_stale = true;
     if (getenv("VBM_DEBUG_NO_JOIN")) return VBM_OK;   // timing experiments only: outputs are not tied to `stream`
     return lazy ? vbm_analysis_round_join_lazy(fe->enc, stream) : vbm_analysis_round_join(fe->enc, stream);

@@ -203,3 +203,32 @@ extern "C" int vbm_launch_untranspose_u8(const uint8_t *srcT, uint8_t *dst_bm, i
 {
     return from_tiled<uint8_t>(srcT, dst_bm, ncols, rows, slab, st);
 }
+
+// ---- timing experiments (VBM_DEBUG_STAMPS=1): device-side time stamps on the internal streams, without a profiler in
+//      the way (rocprofv3 slows the host's graph launches so much that the from-PCM timeline it shows is the host's)
+namespace {
+__global__ void k_stamp(unsigned long long *out, int slot, int tag)
+{
+    out[2 * slot] = (unsigned long long)tag;
+    out[2 * slot + 1] = wall_clock64();      // constant 100 MHz counter
+}
+unsigned long long *g_stamps = nullptr;
+int g_stamp_next = 0, g_stamp_on = -1;
+const int kStampMax = 8192;
+}  // namespace
+extern "C" void vbm_debug_stamp(hipStream_t st, int tag)
+{
+    if (g_stamp_on < 0) g_stamp_on = getenv("VBM_DEBUG_STAMPS") ? 1 : 0;
+    if (!g_stamp_on) return;
+    if (!g_stamps && hipMalloc((void **)&g_stamps, (size_t)kStampMax * 16) != hipSuccess) { g_stamp_on = 0; return; }
+    if (g_stamp_next >= kStampMax) return;
+    hipLaunchKernelGGL(k_stamp, dim3(1), dim3(1), 0, st, g_stamps, g_stamp_next++, tag);
+}
+extern "C" int vbm_debug_stamps_read(unsigned long long *out, int max_pairs)
+{
+    if (!g_stamps) return 0;
+    (void)hipDeviceSynchronize();
+    const int n = g_stamp_next < max_pairs ? g_stamp_next : max_pairs;
+    (void)hipMemcpy(out, g_stamps, (size_t)n * 16, hipMemcpyDeviceToHost);
+    return n;
+}
