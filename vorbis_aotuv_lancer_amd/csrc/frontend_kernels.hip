@@ -40,7 +40,18 @@ __global__ void k_fe_append(vbm_fe_state f, const float *__restrict__ src, int v
     if (f.base[s] + f.pcm_current[s] + vals > f.cap) return;   // full (k_fe_commit counts it): never write past the buffer
     float *dst = f.pcm + (long)f.parity[s] * f.plane + (long)c * f.cap + f.base[s] + f.pcm_current[s];
     const float *in = src + (long)c * vals;
-    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < vals; i += gridDim.y * blockDim.x)
+    const int t0 = blockIdx.y * blockDim.x + threadIdx.x, step = gridDim.y * blockDim.x;
+    if ((((uintptr_t)dst | (uintptr_t)in) & 15) == 0 && (vals & 3) == 0) {      // 16 bytes per thread and step
+        const float4 *in4 = reinterpret_cast<const float4 *>(in);
+        float4 *dst4 = reinterpret_cast<float4 *>(dst);
+        for (int i = t0; i < vals / 4; i += step) {
+            float4 v = in4[i];
+            v.x *= pre_amplitude; v.y *= pre_amplitude; v.z *= pre_amplitude; v.w *= pre_amplitude;   // lib/block.c:514-518
+            dst4[i] = v;
+        }
+        return;
+    }
+    for (int i = t0; i < vals; i += step)
         dst[i] = in[i] * pre_amplitude;             // lib/block.c:514-518
 }
 
@@ -256,9 +267,18 @@ __device__ __forceinline__ float fe_todB(float x)
 // streams per wavefront): lane jb < 12 owns band jb of the detector, lane 0 also the near-DC ring; the
 // 32 smoothed spectrum values of a (step, channel) are produced two per lane and shared through LDS.
 // The steps of a stream stay in order (ve->stretch couples them), channels and bands run side by side.
+//
+// The walk is a chain: every (step, channel) reads and updates the band's amplitude ring (VE_AMP entries, up to 13
+// of them read back per step) and the near-DC ring.  In HBM a ring's entries lie megabytes apart ([entry][channel]
+// [band]), so every read was a round trip of its own, 3 .. 13 in a row per step: ~18 us per (step, channel), 0.57 ms
+// per write of 16384 stereo streams.  Both rings and their cursors are therefore brought into LDS once at the start
+// (all loads in flight together), walked there, and written back at the end; the spectrum values of the next
+// (step, channel) are fetched while the current one is worked on.
+// LDS per stream: ch x (VE_AMP x 16 + 16 + 16 + 4) floats (dynamic: 4 streams per workgroup).
 __global__ __launch_bounds__(64) void k_fe_ve_filter(vbm_fe_state f, const vbm_setup *__restrict__ setup, int t0)
 {
     __shared__ float s_vec[4][32];
+    extern __shared__ float s_ring[];
     const int grp = threadIdx.x >> 4, jb = threadIdx.x & 15;
     const int s = blockIdx.x * 4 + grp;
     if (s >= f.S) return;
@@ -266,6 +286,7 @@ __global__ __launch_bounds__(64) void k_fe_ve_filter(vbm_fe_state f, const vbm_s
     const long SC = (long)f.S * f.ch;
     const int first = f.ve_first[s] + t0, last = f.ve_last[s];
     if (first >= last) return;
+    const int ch = f.ch;
     const float minV = ve->minenergy;
     const float stretch_penalty = ve->stretch_penalty;
     int ve_stretch = f.ve_stretch[s];
@@ -279,132 +300,188 @@ __global__ __launch_bounds__(64) void k_fe_ve_filter(vbm_fe_state f, const vbm_s
 #pragma unroll
     for (int i = 0; i < VBM_VE_MAXBAND; i++) bw[i] = band ? ve->band_window[jb][i] : 0.f;
 
-    for (int t = 0; t < VBM_FE_CHUNK; t++) {
+    // ---- the stream's rings into LDS: per channel amp[VE_AMP][16], ampptr[16], nearDC[16 (15 used)], near state[4]
+    constexpr int PER_CH = VBM_VE_AMP * 16 + 16 + 16 + 4;
+    float *R = s_ring + (size_t)grp * ch * PER_CH;
+    for (int ci = 0; ci < ch; ci++) {
+        const long c = (long)s * ch + ci;
+        float *rc = R + ci * PER_CH;
+#pragma unroll
+        for (int k = 0; k < VBM_VE_AMP; k++) rc[k * 16 + jb] = f.ve_ampbuf[((long)k * SC + c) * 16 + jb];
+        reinterpret_cast<int *>(rc + VBM_VE_AMP * 16)[jb] = f.ve_ampptr[c * 16 + jb];
+        if (jb < VBM_VE_NEARDC) rc[VBM_VE_AMP * 16 + 16 + jb] = f.ve_nearDC[(long)jb * SC + c];
+        if (jb == 0) {
+            float *ns = rc + VBM_VE_AMP * 16 + 32;
+            ns[0] = f.ve_nearacc[c];
+            ns[1] = f.ve_nearacc[SC + c];
+            reinterpret_cast<int *>(ns)[2] = f.ve_nearptr[c];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+    const int nsteps = (last - first < VBM_FE_CHUNK) ? last - first : VBM_FE_CHUNK;
+    const int total_it = nsteps * ch;
+    // spectrum values of (step t, channel ci): two per lane, three more for lane 0
+    auto spec_of = [&](int it) { return f.ve_spec + (((long)s * ch + it % ch) * VBM_FE_CHUNK + it / ch) * 64; };
+    float na = 0.f, nbq = 0.f, na2 = 0.f, nbq2 = 0.f, nh0 = 0.f, nh1 = 0.f, nh2 = 0.f;
+    auto fetch = [&](int it) {
+        const float *sp = spec_of(it);
+        na = sp[2 * jb]; nbq = sp[2 * jb + 1];
+        na2 = sp[2 * (jb + 16)]; nbq2 = sp[2 * (jb + 16) + 1];
+        if (jb == 0) { nh0 = sp[0]; nh1 = sp[1]; nh2 = sp[2]; }
+    };
+    fetch(0);
+
+    int ret = 0, stretch = 0;
+    float penalty = 0.f;
+    for (int it = 0; it < total_it; it++) {
+        const int t = it / ch, ci = it - t * ch;
         const int j = first + t;
-        if (j >= last) break;
-        int ret = 0;
+        if (ci == 0) {
+            ret = 0;
+            ve_stretch++;
+            if (ve_stretch > VBM_VE_MAXSTRETCH * 2) ve_stretch = VBM_VE_MAXSTRETCH * 2;
 
-        ve_stretch++;
-        if (ve_stretch > VBM_VE_MAXSTRETCH * 2) ve_stretch = VBM_VE_MAXSTRETCH * 2;
+            // _ve_amp prologue (lib/envelope.c:112-119)
+            stretch = ve_stretch / 2;
+            if (stretch < VBM_VE_MINSTRETCH) stretch = VBM_VE_MINSTRETCH;
+            penalty = stretch_penalty - (ve_stretch / 2 - VBM_VE_MINSTRETCH);
+            if (penalty < 0.f) penalty = 0.f;
+            if (penalty > stretch_penalty) penalty = stretch_penalty;
+        }
+        const float a = na, bq = nbq, a2 = na2, bq2 = nbq2, h0 = nh0, h1 = nh1, h2 = nh2;
+        if (it + 1 < total_it) fetch(it + 1);
 
-        // _ve_amp prologue (lib/envelope.c:112-119)
-        int stretch = ve_stretch / 2;
-        if (stretch < VBM_VE_MINSTRETCH) stretch = VBM_VE_MINSTRETCH;
-        float penalty = stretch_penalty - (ve_stretch / 2 - VBM_VE_MINSTRETCH);
-        if (penalty < 0.f) penalty = 0.f;
-        if (penalty > stretch_penalty) penalty = stretch_penalty;
+        float *rc = R + ci * PER_CH;
+        float decay = 0.f;
 
-        for (int ci = 0; ci < f.ch; ci++) {
-            const long c = (long)s * f.ch + ci;
-            const float *spec = f.ve_spec + (c * VBM_FE_CHUNK + t) * 64;
-            float decay = 0.f;
-
-            // near-DC spreading function (:127-148), lane 0 of the group
-            if (jb == 0) {
-                const float h0 = spec[0], h1 = spec[1], h2 = spec[2];
-                float temp = (float)((double)(h0 * h0) + (.7 * (double)h1) * (double)h1 + (.2 * (double)h2) * (double)h2);
-                int ptr = f.ve_nearptr[c];
-                float acc = f.ve_nearacc[c], pacc = f.ve_nearacc[SC + c];
-                if (ptr == 0) {
-                    decay = acc = pacc + temp;
-                    pacc = temp;
-                } else {
-                    decay = acc += temp;
-                    pacc += temp;
-                }
-                acc -= f.ve_nearDC[(long)ptr * SC + c];
-                f.ve_nearDC[(long)ptr * SC + c] = temp;
-                f.ve_nearacc[c] = acc;
-                f.ve_nearacc[SC + c] = pacc;
-                decay = (float)((double)decay * (1. / (VBM_VE_NEARDC + 1)));
-                ptr++;
-                if (ptr >= VBM_VE_NEARDC) ptr = 0;
-                f.ve_nearptr[c] = ptr;
-                decay = (float)((double)fe_todB(decay) * .5 - (double)15.f);
+        // near-DC spreading function (:127-148), lane 0 of the group
+        if (jb == 0) {
+            float *dc = rc + VBM_VE_AMP * 16 + 16;
+            float *ns = rc + VBM_VE_AMP * 16 + 32;
+            float temp = (float)((double)(h0 * h0) + (.7 * (double)h1) * (double)h1 + (.2 * (double)h2) * (double)h2);
+            int ptr = reinterpret_cast<int *>(ns)[2];
+            float acc = ns[0], pacc = ns[1];
+            if (ptr == 0) {
+                decay = acc = pacc + temp;
+                pacc = temp;
+            } else {
+                decay = acc += temp;
+                pacc += temp;
             }
-            decay = __shfl(decay, threadIdx.x & 48);   // from lane 0 of this 16-lane group
+            acc -= dc[ptr];
+            dc[ptr] = temp;
+            ns[0] = acc;
+            ns[1] = pacc;
+            decay = (float)((double)decay * (1. / (VBM_VE_NEARDC + 1)));
+            ptr++;
+            if (ptr >= VBM_VE_NEARDC) ptr = 0;
+            reinterpret_cast<int *>(ns)[2] = ptr;
+            decay = (float)((double)fe_todB(decay) * .5 - (double)15.f);
+        }
+        decay = __shfl(decay, threadIdx.x & 48);   // from lane 0 of this 16-lane group
 
-            // spreading, limiting, spectrum smoothing (:151-159): value k uses decay after k subtractions of 8
-            // (subtracted one at a time, as the source rounds after each)
+        // spreading, limiting, spectrum smoothing (:151-159): value k uses decay after k subtractions of 8
+        // (subtracted one at a time, as the source rounds after each)
+        {
+            float dk = decay;
+            for (int k = 0; k < 32; k++) {
+                if (k == jb || k == jb + 16) {
+                    const float x = (k == jb) ? a : a2, y = (k == jb) ? bq : bq2;
+                    float val = x * x + y * y;
+                    val = fe_todB(val) * .5f;
+                    if (val < dk) val = dk;
+                    if (val < minV) val = minV;
+                    s_vec[grp][k] = val;
+                }
+                dk = (float)((double)dk - 8.);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+        // preecho / postecho triggering by band (:162-559 scalar), one band per lane
+        if (band) {
+            float acc = 0.f;
+            for (int i = 0; i < end; i++) acc += s_vec[grp][i + begin] * bw[i];
+            acc *= total;
+
+            float *ampbuf = rc + jb;                               // element k at [k * 16]
+            int *aptr = reinterpret_cast<int *>(rc + VBM_VE_AMP * 16) + jb;
+            const int cur = *aptr;
+            float postmax, postmin, premax = -99999.f, premin = 99999.f;
+            int p = cur;
+            p--;
+            if (p < 0) p += VBM_VE_AMP;
             {
-                float dk = decay;
-                for (int k = 0; k < 32; k++) {
-                    if (k == jb || k == jb + 16) {
-                        const float a = spec[2 * k], bq = spec[2 * k + 1];
-                        float val = a * a + bq * bq;
-                        val = fe_todB(val) * .5f;
-                        if (val < dk) val = dk;
-                        if (val < minV) val = minV;
-                        s_vec[grp][k] = val;
-                    }
-                    dk = (float)((double)dk - 8.);
-                }
+                const float v = ampbuf[p * 16];
+                postmax = acc > v ? acc : v;
+                postmin = acc < v ? acc : v;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-
-            // preecho / postecho triggering by band (:162-559 scalar), one band per lane
-            if (band) {
-                float acc = 0.f;
-                for (int i = 0; i < end; i++) acc += s_vec[grp][i + begin] * bw[i];
-                acc *= total;
-
-                float *ampbuf = f.ve_ampbuf + c * 16 + jb;           // element k at [k * SC * 16]
-                const long kstride = SC * 16;
-                const int cur = f.ve_ampptr[c * 16 + jb];
-                float postmax, postmin, premax = -99999.f, premin = 99999.f;
-                int p = cur;
+            for (int i = 0; i < stretch; i++) {
                 p--;
                 if (p < 0) p += VBM_VE_AMP;
-                {
-                    const float a = ampbuf[(long)p * kstride];
-                    postmax = acc > a ? acc : a;
-                    postmin = acc < a ? acc : a;
-                }
-                for (int i = 0; i < stretch; i++) {
-                    p--;
-                    if (p < 0) p += VBM_VE_AMP;
-                    const float a = ampbuf[(long)p * kstride];
-                    premax = premax > a ? premax : a;
-                    premin = premin < a ? premin : a;
-                }
-                const float valmin = postmin - premin;
-                const float valmax = postmax - premax;
-
-                ampbuf[(long)cur * kstride] = acc;
-                int np = cur + 1;
-                if (np >= VBM_VE_AMP) np = 0;
-                f.ve_ampptr[c * 16 + jb] = np;
-
-                if (valmax > pre_t + penalty) ret |= 1 | 4;
-                if (valmin < post_t - penalty) ret |= 2;
+                const float v = ampbuf[p * 16];
+                premax = premax > v ? premax : v;
+                premin = premin < v ? premin : v;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const float valmin = postmin - premin;
+            const float valmax = postmax - premax;
+
+            ampbuf[cur * 16] = acc;
+            int np = cur + 1;
+            if (np >= VBM_VE_AMP) np = 0;
+            *aptr = np;
+
+            if (valmax > pre_t + penalty) ret |= 1 | 4;
+            if (valmin < post_t - penalty) ret |= 2;
         }
-        // OR over the 16 lanes of the group
-        ret |= __shfl_xor(ret, 1);
-        ret |= __shfl_xor(ret, 2);
-        ret |= __shfl_xor(ret, 4);
-        ret |= __shfl_xor(ret, 8);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
-        // mark bookkeeping of _ve_envelope_search (lib/envelope.c:611-624)
-        if (jb == 0) {
-            f.ve_mark[(long)(j + VBM_VE_POST) * S + s] = 0;
-            if (ret & 1) {
-                f.ve_mark[(long)j * S + s] = 1;
-                f.ve_mark[(long)(j + 1) * S + s] = 1;
+        if (ci == ch - 1) {
+            // OR over the 16 lanes of the group
+            ret |= __shfl_xor(ret, 1);
+            ret |= __shfl_xor(ret, 2);
+            ret |= __shfl_xor(ret, 4);
+            ret |= __shfl_xor(ret, 8);
+
+            // mark bookkeeping of _ve_envelope_search (lib/envelope.c:611-624)
+            if (jb == 0) {
+                f.ve_mark[(long)(j + VBM_VE_POST) * S + s] = 0;
+                if (ret & 1) {
+                    f.ve_mark[(long)j * S + s] = 1;
+                    f.ve_mark[(long)(j + 1) * S + s] = 1;
+                }
+                if (ret & 2) {
+                    f.ve_mark[(long)j * S + s] = 1;
+                    if (j > 0) f.ve_mark[(long)(j - 1) * S + s] = 1;
+                }
             }
-            if (ret & 2) {
-                f.ve_mark[(long)j * S + s] = 1;
-                if (j > 0) f.ve_mark[(long)(j - 1) * S + s] = 1;
-            }
+            if (ret & 4) ve_stretch = -1;
         }
-        if (ret & 4) ve_stretch = -1;
     }
     if (jb == 0) f.ve_stretch[s] = ve_stretch;
+
+    // ---- rings back
+    for (int ci = 0; ci < ch; ci++) {
+        const long c = (long)s * ch + ci;
+        const float *rc = R + ci * PER_CH;
+#pragma unroll
+        for (int k = 0; k < VBM_VE_AMP; k++) f.ve_ampbuf[((long)k * SC + c) * 16 + jb] = rc[k * 16 + jb];
+        f.ve_ampptr[c * 16 + jb] = reinterpret_cast<const int *>(rc + VBM_VE_AMP * 16)[jb];
+        if (jb < VBM_VE_NEARDC) f.ve_nearDC[(long)jb * SC + c] = rc[VBM_VE_AMP * 16 + 16 + jb];
+        if (jb == 0) {
+            const float *ns = rc + VBM_VE_AMP * 16 + 32;
+            f.ve_nearacc[c] = ns[0];
+            f.ve_nearacc[SC + c] = ns[1];
+            f.ve_nearptr[c] = reinterpret_cast<const int *>(ns)[2];
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -728,7 +805,7 @@ __global__ void k_fe_flip(vbm_fe_state f, const vbm_fe_decision *__restrict__ de
 
 extern "C" int vbm_fe_launch_append(const vbm_fe_state *f, const float *d_src, int vals, float pre_amplitude, hipStream_t st)
 {
-    const unsigned gx = (unsigned)((vals + 255) / 256);
+    const unsigned gx = (unsigned)((vals + 1023) / 1024);       // a thread moves 16 bytes per step
     hipLaunchKernelGGL(k_fe_append, dim3((unsigned)(f->S * f->ch), gx ? gx : 1), dim3(256), 0, st, *f, d_src, vals, pre_amplitude);
     hipLaunchKernelGGL(k_fe_commit, dim3((unsigned)((f->S + 255) / 256)), dim3(256), 0, st, *f, vals);
     return CHECK_LAUNCH();
@@ -769,7 +846,9 @@ extern "C" int vbm_fe_launch_ve_range(const vbm_fe_state *f, hipStream_t st)
 
 extern "C" int vbm_fe_launch_ve_filter(const vbm_fe_state *f, const vbm_setup *d_setup, int t0, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_fe_ve_filter, dim3((unsigned)((f->S + 3) / 4)), dim3(64), 0, st, *f, d_setup, t0);
+    const size_t lds = (size_t)4 * f->ch * (VBM_VE_AMP * 16 + 16 + 16 + 4) * sizeof(float);   // the rings of four streams
+    if (lds > 60 * 1024) return -2;       // (more than 12 channels: not a Vorbis I mapping this encoder sets up)
+    hipLaunchKernelGGL(k_fe_ve_filter, dim3((unsigned)((f->S + 3) / 4)), dim3(64), lds, st, *f, d_setup, t0);
     return CHECK_LAUNCH();
 }
 
