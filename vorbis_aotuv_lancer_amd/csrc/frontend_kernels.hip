@@ -317,10 +317,12 @@ __global__ __launch_bounds__(64) void k_fe_ve_filter(vbm_fe_state f, const vbm_s
             reinterpret_cast<int *>(ns)[2] = f.ve_nearptr[c];
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+    // (the lanes of a stream share a wavefront: its LDS accesses are performed in program order, so the exchanges
+    // below need the compiler to keep that order — a wavefront-scope fence — and no wait for memory)
     const int nsteps = (last - first < VBM_FE_CHUNK) ? last - first : VBM_FE_CHUNK;
     const int total_it = nsteps * ch;
     // spectrum values of (step t, channel ci): two per lane, three more for lane 0
@@ -399,9 +401,9 @@ __global__ __launch_bounds__(64) void k_fe_ve_filter(vbm_fe_state f, const vbm_s
                 dk = (float)((double)dk - 8.);
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
         // preecho / postecho triggering by band (:162-559 scalar), one band per lane
         if (band) {
@@ -439,9 +441,9 @@ __global__ __launch_bounds__(64) void k_fe_ve_filter(vbm_fe_state f, const vbm_s
             if (valmax > pre_t + penalty) ret |= 1 | 4;
             if (valmin < post_t - penalty) ret |= 2;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
         if (ci == ch - 1) {
             // OR over the 16 lanes of the group
