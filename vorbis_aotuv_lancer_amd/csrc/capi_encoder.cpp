@@ -99,7 +99,9 @@ struct vbm_encoder {
     // long blocks) batches, gq[2] their back halves.  A group = the launches of one of them for one workspace,
     // captured the second time it is needed and replayed from then on.
     struct round_graph { hipGraphExec_t exec = nullptr; int uses = 0; };
-    round_graph gJ[kMaxWS][4][3];          // [workspace][block type][0 whole pipeline, 1 front half, 2 back half]
+    // [workspace][block type; 4 = the big batch (type 3, first round): its launches differ from a small type-3 batch's
+    // (throughput variants of the kernels, own streams)][0 whole pipeline, 1 front half, 2 back half]
+    round_graph gJ[kMaxWS][5][3];
     hipEvent_t ev_state_big[kMaxWS] = {};  // front half of the big batch run in the workspace
     int queue_last_w[4] = {-1, -1, -1, -1};   // workspace of the newest job on sub[0..3]
     bool small_streams_set = false, small_share = false;
@@ -163,7 +165,7 @@ extern "C" void vbm_encoder_destroy(vbm_encoder *e)
     if (!e) return;
     for (void *p : e->allocs) (void)hipFree(p);
     for (int i = 0; i < kMaxWS; i++) {
-        for (int m = 0; m < 4; m++)
+        for (int m = 0; m < 5; m++)
             for (int k = 0; k < 3; k++)
                 if (e->gJ[i][m][k].exec) (void)hipGraphExecDestroy(e->gJ[i][m][k].exec);
         if (e->ev_state_big[i]) (void)hipEventDestroy(e->ev_state_big[i]);
@@ -1258,12 +1260,12 @@ static int device_round_run_graphs(vbm_encoder *e, int w, const int *lane0, cons
         if ((rc = wait_preds(qF, 3, 4))) return rc;
         type_job jf = job_of(3, 1), jb = job_of(3, 2);
         vbm_debug_stamp(qF, 10);
-        if ((rc = run_group(e, e->gJ[w][3][1], qF, &jf, 1, 1))) return rc;
+        if ((rc = run_group(e, e->gJ[w][4][1], qF, &jf, 1, 1))) return rc;
         vbm_debug_stamp(qF, 11);
         if ((err = hipEventRecord(e->ev_state_big[w], qF)) != hipSuccess ||
             (err = hipStreamWaitEvent(qB, e->ev_state_big[w], 0)) != hipSuccess) return vbm_set_hip_error(err, "big batch hand-over");
         vbm_debug_stamp(qB, 12);
-        if ((rc = run_group(e, e->gJ[w][3][2], qB, &jb, 1, 2))) return rc;
+        if ((rc = run_group(e, e->gJ[w][4][2], qB, &jb, 1, 2))) return rc;
         if ((rc = copy_outputs(e, jb, qB))) return rc;
         vbm_debug_stamp(qB, 13);
         if ((err = hipEventRecord(e->ev_done[w][3], qB)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
