@@ -271,6 +271,8 @@ def main():
         counting = [False]
 
         DEVICE_ROUNDS = os.environ.get("VBM_BENCH_DEVICE_ROUNDS", "1") != "0"
+        CONSUMER = os.environ.get("VBM_BENCH_CONSUMER", "1") != "0"
+        consumer = torch.cuda.Stream(device=dev) if CONSUMER else None
         # rounds per write, cycled: a stream needs ~1.2 blocks per 1024 samples at this signal's block-switching rate
         # (55 long + 10 short + 2 transition blocks per 57 writes), a stream inside a burst eight; streams that fell
         # behind catch up one extra block per round.  "2,1" (1.5 per write) keeps every stream's buffer bounded over
@@ -285,7 +287,14 @@ def main():
                 nr = 3 if k < args.warmup else PATTERN[k % len(PATTERN)]
                 if counting[0]:
                     stat["rounds"] += nr
-                kept.append(fe.encode_rounds_device(nrounds=nr, lazy=LAZY_JOIN, device=dev))
+                # lazy=2: the stream that feeds PCM never waits for packets; a consumer's stream is tied to the outputs of
+                # every call instead (what a writer of Ogg pages would wait on).  VBM_BENCH_CONSUMER=0: the feeding
+                # stream itself waits (lazy join: all but the newest long-block batch and the last round).
+                if CONSUMER:
+                    kept.append(fe.encode_rounds_device(nrounds=nr, lazy=2, device=dev))
+                    fe.join(consumer)
+                else:
+                    kept.append(fe.encode_rounds_device(nrounds=nr, lazy=LAZY_JOIN, device=dev))
                 del kept[:-6]
                 return
             info, pk_, nb_, counts = fe.encode_rounds(min_rounds=MIN_ROUNDS, max_rounds=16, headroom=HOP, device=dev,
@@ -455,6 +464,8 @@ def main():
             line["config"].update({
                 "blocks_encoded": st["blocks"], "rounds": st["rounds"], "rounds_per_write": st["rounds"] / args.steps,
                 "rounds_pattern": os.environ.get("VBM_BENCH_ROUNDS", "2,1"),
+                "outputs_joined_on": ("a consumer stream after every call (the feeding stream never waits for packets)"
+                                      if os.environ.get("VBM_BENCH_CONSUMER", "1") != "0" else "the feeding stream (lazy join)"),
                 "blocks_by_mode": {"impulse_short": int(st["modes"][0]), "padding_short": int(st["modes"][1]),
                                    "transition_long": int(st["modes"][2]), "long": int(st["modes"][3])},
                 "short_block_fraction": float(st["modes"][:2].sum() / max(st["blocks"], 1)),

@@ -298,16 +298,18 @@ int vbm_frontend_join(vbm_frontend *fe, void *stream);
  * what came out from the outputs, when it chooses to look.
  *   Layout: a round has vbm_device_round_lanes() output slots ("lanes").  Block type m owns a fixed region of
  *   them (the impulse, padding and transition blocks a quarter of the stream count each, then the long blocks with
- *   one lane per stream); inside a region the blocks follow in ascending stream order.  A stream whose type's region is full keeps its block for the next round,
- *   and the streams of a call's first long-block batch get no further block in that call (rounds may be deferred:
- *   blocks and packets do not depend on when they run).
+ *   one lane per stream); inside a region the blocks follow in ascending stream order.  A stream whose type's region is
+ *   full keeps its block for the next round (rounds may be deferred: blocks and packets do not depend on when they
+ *   run); a stream that has fallen behind its input delivers a block in every round of a call until it has caught up.
  *   nrounds rounds per call; round r writes
  *     d_packets      [r][lane][max_packet_bytes]   (may be NULL)
  *     d_packet_bytes [r][lane]   length, -2 = no block in this lane, -1 = packet outgrew the buffer
  *     d_info         [r][lane]   vbm_packet_info of the lane's block (stream = -1: none); device or pinned host memory
  *     d_counts       [r][4]      blocks of each type (device memory: the round's kernels read it while they run)
- *   all complete on `stream` when the call's work has run (lazy != 0: the long-block batch of the call only after
- *   the next call or vbm_frontend_join, as vbm_frontend_encode_rounds_lazy).  The buffers belong to the call until then.
+ *   all complete on `stream` when the call's work has run (lazy = 1: the long-block batch of the call only after
+ *   the next call or vbm_frontend_join, as vbm_frontend_encode_rounds_lazy; lazy = 2: nothing is tied to `stream` by
+ *   the call — a consumer calls vbm_frontend_join(fe, its_stream) before it reads, so the stream that feeds PCM never
+ *   waits for packets).  The buffers belong to the call until then.
  *   The encoder must have been created with max_batch >= vbm_device_round_lanes(setup, nstreams).
  * Mixing with the host-built rounds above is allowed (e.g. to drain completely before vbm_frontend_finish): the first
  * such call waits for the front end's stream and fetches the buffer fills it needs.  While only device-built rounds

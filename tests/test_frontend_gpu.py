@@ -393,11 +393,13 @@ def collect_device(sink, fe, out):
 
 @pytest.mark.parametrize("ch,rate,q,NS,lazy", [(2, 44100, 0.5, 70, False), (2, 44100, 0.5, 70, True), (2, 44100, 0.5, 1100, False),
                                                (2, 44100, 0.5, 1100, True), (6, 48000, 0.8, 9, False),
-                                               (1, 8000, 0.5, 6, False), (2, 44100, -0.1, 5, False)])
+                                               (1, 8000, 0.5, 6, False), (2, 44100, -0.1, 5, False),
+                                               (2, 44100, 0.5, 1100, 2)])
 def test_device_built_rounds(oracle, cuda, monkeypatch, ch, rate, q, NS, lazy):
-    """Two device-built rounds per 1024-sample write, outputs read one call late when lazy; then the host-built
-    rounds drain what is left and end the streams.  Per stream, in order: block flags, granule positions, packet
-    numbers and packet bytes of the oracle."""
+    """Two device-built rounds per 1024-sample write, outputs read one call late when lazy (lazy = 2: the feeding
+    stream is never tied to the outputs; a consumer stream joins before it reads); then the host-built rounds drain
+    what is left and end the streams.  Per stream, in order: block flags, granule positions, packet numbers and
+    packet bytes of the oracle."""
     import vorbis_aotuv_lancer_amd as v
     monkeypatch.setenv("VBM_WORKSPACES", "4")
     K = min(NS, 7)
@@ -430,13 +432,19 @@ def test_device_built_rounds(oracle, cuda, monkeypatch, ch, rate, q, NS, lazy):
         fe.write(allp[:, :, at:at + 1024].contiguous())
         # (two rounds per write keep up with 256/2048 switching; 512-sample blocks at one size come 4 per write)
         out = fe.encode_rounds_device(nrounds=2 if setup.blocksizes[0] != setup.blocksizes[1] else 5, lazy=lazy)
-        if lazy:
+        if lazy == 2:
+            consumer = getattr(test_device_built_rounds, "_consumer", None) or torch.cuda.Stream(device=cuda)
+            test_device_built_rounds._consumer = consumer
+            fe.join(consumer)
+            with torch.cuda.stream(consumer):
+                total += collect_device(got, fe, out)
+        elif lazy:
             if held is not None:
                 total += collect_device(got, fe, held)
             held = out
         else:
             total += collect_device(got, fe, out)
-    if lazy:
+    if lazy and lazy != 2:
         fe.join()
         total += collect_device(got, fe, held)
     modes, samples = fe.device_stats()

@@ -771,7 +771,7 @@ extern "C" int vbm_frontend_encode_rounds_device(vbm_frontend *fe, int nrounds, 
     }
     vbm_debug_stamp(q, 4);
     fe->mirrors_stale = true;
-    if (getenv("VBM_DEBUG_NO_JOIN")) return VBM_OK;   // timing experiments only: outputs are not tied to `stream`
+    if (lazy == 2) return VBM_OK;          // the consumer joins (vbm_frontend_join on its own stream)
     return lazy ? vbm_analysis_round_join_lazy(fe->enc, stream) : vbm_analysis_round_join(fe->enc, stream);
 }
 

@@ -223,9 +223,10 @@ class FrontEnd:
         k = n.value
         return self._info_view[:k], packets[:k], nbytes[:k]
 
-    def join(self):
-        """vbm_frontend_join: the current stream waits for everything begun so far (lazy calls included)"""
-        check(lib.vbm_frontend_join(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "vbm_frontend_join")
+    def join(self, stream=None):
+        """vbm_frontend_join: `stream` (default: the current one) waits for everything begun so far (lazy calls included)"""
+        st = stream if stream is not None else torch.cuda.current_stream()
+        check(lib.vbm_frontend_join(self._h, C.c_void_p(st.cuda_stream)), "vbm_frontend_join")
 
     def encode_rounds(self, min_rounds=1, max_rounds=8, headroom=1024, device=None, lazy=False, cap_blocks=None):
         """Up to max_rounds blockout rounds in one call (vbm_frontend_encode_rounds: a round runs beside the
@@ -272,7 +273,8 @@ class FrontEnd:
         Returns device tensors (info uint8 [nrounds * lanes, 40] = vbm_packet_info records, packets uint8
         [nrounds * lanes, max_bytes], nbytes int32 [nrounds * lanes] with -2 = empty lane, counts int32 [nrounds, 4]),
         complete on the current stream when the call's work has run (lazy: the call's long-block batch one call
-        later).  They live in a ring of three sets owned by this object."""
+        later; lazy=2: not tied to the current stream at all — a consumer calls join(stream) before it reads).  They
+        live in a ring of three sets per round count owned by this object."""
         dev = device or torch.device("cuda", torch.cuda.current_device())
         lanes = self.device_lanes
         rings = getattr(self, "_drings", None)
@@ -291,7 +293,7 @@ class FrontEnd:
         info, packets, nbytes, counts = ring[0][at]
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         check(lib.vbm_frontend_encode_rounds_device(self._h, nrounds, packets.data_ptr(), nbytes.data_ptr(), info.data_ptr(),
-                                                    counts.data_ptr(), 1 if lazy else 0, st),
+                                                    counts.data_ptr(), int(lazy), st),
               "vbm_frontend_encode_rounds_device")
         return info, packets, nbytes, counts
 
