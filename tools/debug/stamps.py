@@ -18,10 +18,12 @@ N = 40
 chunks = [bench.synth_pcm(torch, dev, params, gen, k * 1024, 1024) for k in range(N)]
 torch.cuda.synchronize()
 kept = []
+consumer = torch.cuda.Stream(device=dev)
 pat = [int(x) for x in os.environ.get("VBM_BENCH_ROUNDS", "2,1").split(",")]
 for k in range(N):
     fe.write(chunks[k])
-    kept.append(fe.encode_rounds_device(nrounds=3 if k < 8 else pat[k % len(pat)], lazy=True)); del kept[:-6]
+    kept.append(fe.encode_rounds_device(nrounds=3 if k < 8 else pat[k % len(pat)], lazy=2)); del kept[:-6]
+    fe.join(consumer)
 torch.cuda.synchronize()
 buf = (C.c_ulonglong * (2 * 8192))()
 n = v.lib.vbm_debug_stamps_read(buf, 8192)

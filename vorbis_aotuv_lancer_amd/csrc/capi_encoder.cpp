@@ -24,7 +24,7 @@
 extern "C" int vbm_launch_spread_flags(const vbm_batch *b, hipStream_t st);
 vbm_setup_host *vbm_setup_handle_host(vbm_setup_handle *h);
 
-static const int kMaxWS = 4;
+static const int kMaxWS = 8;     // (dependency masks hold 4 bits per workspace in 32)
 
 struct vbm_encoder {
     vbm_setup_host *H;
