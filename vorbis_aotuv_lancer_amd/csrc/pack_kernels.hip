@@ -850,7 +850,9 @@ extern "C" int vbm_launch_pack_residue(const vbm_batch *b, hipStream_t st)
     const unsigned tiles = (unsigned)((b->nsb + 63) / 64);
     hipLaunchKernelGGL(k_nonzero_propagate, dim3(tiles), dim3(64), 0, st, *b);
     for (int sm = 0; sm < b->pack_submaps; sm++) {
-        int nchunks = b->pack_partvals[sm] < 32 ? b->pack_partvals[sm] : 32;
+        // (a small batch is bound by the length of a slice's walk: one partition per slice there)
+        const int most = (b->few || b->nsb <= 1024) ? 256 : 32;
+        int nchunks = b->pack_partvals[sm] < most ? b->pack_partvals[sm] : most;
         if (nchunks < 1) nchunks = 1;
         hipLaunchKernelGGL(k_res_vq, dim3(tiles, (unsigned)nchunks), dim3(64), (size_t)b->pack_spp[sm] * 64 * sizeof(int), st, *b,
                            sm, nchunks);
