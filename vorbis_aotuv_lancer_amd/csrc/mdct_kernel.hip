@@ -145,11 +145,13 @@ __device__ __forceinline__ const float *block_src(const float *__restrict__ pcm,
 }
 
 // group of eight 16-B loads -> registers
+// returns whether any block of the group exists (wave-uniform): a group without one is skipped
 template <int N, bool GATHER>
-__device__ __forceinline__ void issue_loads(float4 (&v)[8], const float *__restrict__ pcm,
+__device__ __forceinline__ bool issue_loads(float4 (&v)[8], const float *__restrict__ pcm,
                                             long group, long nblocks, int lane, const vbm_ve_gather &g)
 {
     using G = Geo<N>;
+    bool any = false;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         int P = lane + 64 * k;
@@ -157,11 +159,13 @@ __device__ __forceinline__ void issue_loads(float4 (&v)[8], const float *__restr
         int q0 = (p < G::R2) ? (G::R2 - 1 - p) : (7 * N / 16 - 1 - p);
         long blk = group * G::BPG + b;
         const float *src = (blk < nblocks) ? block_src<GATHER>(pcm, blk, N, g) : nullptr;
-        if (src)
+        if (src) {
             v[k] = *reinterpret_cast<const float4 *>(src + 4 * q0);
-        else
+            any = true;
+        } else
             v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    return __any(any);
 }
 
 // Radix rounds A, B, C on one 512-complex group held as c[k] = element lane + 64k: the butterfly stages of
@@ -330,9 +334,17 @@ void k_window_mdct(const float *__restrict__ pcm, float *__restrict__ out,
     const float scale = 4.f / N;
 
     float4 v[8];
-    if (group < ngroups) issue_loads<N, GATHER>(v, pcm, group, nblocks, lane, gather);
+    bool have = false;
+    if (group < ngroups) have = issue_loads<N, GATHER>(v, pcm, group, nblocks, lane, gather);
 
     for (; group < ngroups; group += gstride) {
+        if (!have) {
+            // none of the group's blocks exists (the envelope search covers 32 steps per channel and launch, a
+            // 1024-sample write brings 16): nothing to transform, nothing to store
+            const long nx = group + gstride;
+            have = (nx < ngroups) ? issue_loads<N, GATHER>(v, pcm, nx, nblocks, lane, gather) : false;
+            continue;
+        }
         // ---------------- window + odd-sample exchange -----------------------------
         float2 ev[8];
 #pragma unroll
@@ -380,7 +392,7 @@ void k_window_mdct(const float *__restrict__ pcm, float *__restrict__ out,
             c[k].x = r1 * T.y + r0 * T.x;
             c[k].y = r1 * T.x - r0 * T.y;
         }
-        if (next < ngroups) issue_loads<N, GATHER>(v, pcm, next, nblocks, lane, gather);
+        have = (next < ngroups) ? issue_loads<N, GATHER>(v, pcm, next, nblocks, lane, gather) : false;
         wave_lds_sync();  // exchange slots are reused below
 
         radix_rounds<G::LOG2C>(c, sx, s_trig, lane);
