@@ -396,15 +396,32 @@ def collect_device(sink, fe, out):
                                                (1, 8000, 0.5, 6, False), (2, 44100, -0.1, 5, False),
                                                (2, 44100, 0.5, 1100, 2)])
 def test_device_built_rounds(oracle, cuda, monkeypatch, ch, rate, q, NS, lazy):
+    run_device_built_rounds(oracle, cuda, monkeypatch, ch, rate, q, NS, lazy, min(NS, 7))
+
+
+def test_device_built_rounds_all_streams_switch_together(oracle, cuda, monkeypatch):
+    """1100 streams with the SAME signal: every burst makes all of them ask for short blocks in the same round, the
+    short types' lane regions (320 lanes) overflow, and most streams are put off — across calls too — and catch up
+    later.  Packets must not depend on when a stream's blocks run."""
+    run_device_built_rounds(oracle, cuda, monkeypatch, 2, 44100, 0.5, 1100, False, 1)
+
+
+def run_device_built_rounds(oracle, cuda, monkeypatch, ch, rate, q, NS, lazy, K):
     """Two device-built rounds per 1024-sample write, outputs read one call late when lazy (lazy = 2: the feeding
     stream is never tied to the outputs; a consumer stream joins before it reads); then the host-built rounds drain
     what is left and end the streams.  Per stream, in order: block flags, granule positions, packet numbers and
     packet bytes of the oracle."""
     import vorbis_aotuv_lancer_amd as v
     monkeypatch.setenv("VBM_WORKSPACES", "4")
-    K = min(NS, 7)
     nsamp = 26 * 1024
     base = [synth_signal(ch, rate, nsamp, seed=730 + k, level=1.0 if k % 3 else 0.05) for k in range(K)]
+    if K == 1:      # a tone with three noise bursts: every burst switches every stream to short blocks at once
+        rng = np.random.default_rng(5)
+        t = np.arange(nsamp) / rate
+        x = np.stack([0.3 * np.sin(2 * np.pi * 440 * t + c) for c in range(ch)]).astype(np.float32)
+        for at in (6000, 13500, 20500):
+            x[:, at:at + 200] += (0.6 * rng.standard_normal((ch, 200))).astype(np.float32)
+        base = [x]
     osetup = orc.Setup(oracle, ch, rate, q)
     want = []
     for k in range(K):
@@ -449,6 +466,9 @@ def test_device_built_rounds(oracle, cuda, monkeypatch, ch, rate, q, NS, lazy):
         total += collect_device(got, fe, held)
     modes, samples = fe.device_stats()
     assert sum(modes) == total
+    assert fe.refused_writes == 0
+    if K == 1:      # the case is only worth its name if short blocks came and a region overflowed
+        assert modes[0] + modes[1] > 2 * NS, modes
     drain(fe, got)                      # host-built rounds take over: the mirrors are fetched from the device
     fe.finish()
     drain(fe, got)

@@ -467,7 +467,13 @@ __global__ __launch_bounds__(64) void k_fe_ve_filter(vbm_fe_state f, const vbm_s
             if (ret & 4) ve_stretch = -1;
         }
     }
-    if (jb == 0) f.ve_stretch[s] = ve_stretch;
+    if (jb == 0) {
+        f.ve_stretch[s] = ve_stretch;
+        // _ve_envelope_search leaves ve->current at the last step it evaluated (lib/envelope.c:627) whether or not a
+        // block comes out of the blockout call: a stream that delivers no block in this call (no data yet, or its
+        // block type's lane region was full in every round) must not have these steps evaluated again by the next
+        if (first + nsteps >= last) f.ve_current[s] = last * 64;
+    }
 
     // ---- rings back
     for (int ci = 0; ci < ch; ci++) {
