@@ -276,7 +276,7 @@ def main():
         # rounds per write, cycled: a stream needs ~1.2 blocks per 1024 samples at this signal's block-switching rate
         # (55 long + 10 short + 2 transition blocks per 57 writes), a stream inside a burst eight; streams that fell
         # behind catch up one extra block per round.  "2,1,1" (1.33 per write) keeps every stream's buffer bounded over
-        # hundreds of writes (300 writes: encoded / input 0.9992, max_buffered_samples_at_end 9280, as with "2,1");
+        # hundreds of writes (300 writes: encoded / input 0.9985, max_buffered_samples_at_end 14528 as after 48);
         # "2,1,1,1" and "1" do not (the buffers grow until a write is refused, which aborts the run).
         # The warm-up runs three per write to clear the start of the streams, where all deliver short blocks at once.
         PATTERN = [int(x) for x in os.environ.get("VBM_BENCH_ROUNDS", "2,1,1").split(",")]

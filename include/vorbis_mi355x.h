@@ -298,7 +298,8 @@ int vbm_frontend_join(vbm_frontend *fe, void *stream);
  * what came out from the outputs, when it chooses to look.
  *   Layout: a round has vbm_device_round_lanes() output slots ("lanes").  Block type m owns a fixed region of
  *   them (the impulse, padding and transition blocks a quarter of the stream count each, then the long blocks with
- *   one lane per stream); inside a region the blocks follow in ascending stream order.  A stream whose type's region is
+ *   one lane per stream — half of them in the later rounds of a call, whose long blocks are those of streams catching
+ *   up); inside a region the blocks follow in ascending stream order.  A stream whose type's region is
  *   full keeps its block for the next round (rounds may be deferred: blocks and packets do not depend on when they
  *   run); a stream that has fallen behind its input delivers a block in every round of a call until it has caught up.
  *   nrounds rounds per call; round r writes

@@ -743,8 +743,17 @@ extern "C" int vbm_frontend_encode_rounds_device(vbm_frontend *fe, int nrounds, 
         float *blocks = fe->d_blocks_dev + (size_t)w * fe->lanes * ch * bs1;
         int *counts_r = d_counts + 4 * r;
         int *bytes_r = d_packet_bytes + (size_t)r * fe->lanes;
+        // Lanes per block type in this round.  The long blocks of a call's LATER rounds are those of streams catching
+        // up: their region is cut to half the streams (every kernel of a batch is launched for the region's size — a
+        // full-size region costs ~40 launches of 16384 mostly empty workgroups; a stream that finds the region full
+        // keeps its block for the next round like any other).  A quarter is too little to keep up at the burst rate of
+        // the bench signal (a burst leaves a stream ~5 long blocks behind: 1437 extra long blocks per write of 16384
+        // streams against 0.33 later rounds per write).
+        int caps[4];
+        for (int m = 0; m < 4; m++) caps[m] = fe->lane_cap[m];
+        if (r > 0 && caps[2] > 0 && caps[3] > 2 * caps[2]) caps[3] = 2 * caps[2];
         vbm_fe_round R;
-        for (int m = 0; m < 4; m++) { R.lane0[m] = fe->lane0[m]; R.cap[m] = fe->lane_cap[m]; }
+        for (int m = 0; m < 4; m++) { R.lane0[m] = fe->lane0[m]; R.cap[m] = caps[m]; }
         R.first_round = r == 0;
         R.count = counts_ws;        // the workspace's own counts: what the round's kernels (and graphs) read
         R.slot = fe->d_slot;
@@ -757,14 +766,14 @@ extern "C" int vbm_frontend_encode_rounds_device(vbm_frontend *fe, int nrounds, 
         if ((err = hipMemcpyAsync(counts_r, counts_ws, 4 * sizeof(int), hipMemcpyDeviceToDevice, q)) != hipSuccess)
             return vbm_set_hip_error(err, "hipMemcpyAsync(counts)");
         for (int m = 0; m < 4; m++) {
-            if (!fe->lane_cap[m]) continue;
+            if (!caps[m]) continue;
             const int N = (m >> 1) ? bs1 : bs0;
-            if (vbm_fe_launch_gather(&fe->f, d_sid + fe->lane0[m], fe->d_begin_lane + fe->lane0[m], fe->lane_cap[m], N,
+            if (vbm_fe_launch_gather(&fe->f, d_sid + fe->lane0[m], fe->d_begin_lane + fe->lane0[m], caps[m], N,
                                      blocks + (size_t)fe->lane0[m] * ch * bs1, counts_ws + m, q))
                 return VBM_EHIP;
         }
         vbm_debug_stamp(q, 2 + (r ? 1 : 0));
-        rc = vbm_encoder_device_round_run(fe->enc, w, fe->lane0, fe->lane_cap, counts_ws, blocks,
+        rc = vbm_encoder_device_round_run(fe->enc, w, fe->lane0, caps, counts_ws, blocks,
                                           d_packets ? d_packets + (size_t)r * fe->lanes * maxb : nullptr, bytes_r, r == 0, q);
         if (rc) return rc;
         if (vbm_fe_launch_shift(&fe->f, fe->d_dec, q)) return VBM_EHIP;
