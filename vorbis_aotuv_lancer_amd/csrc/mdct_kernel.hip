@@ -136,12 +136,12 @@ __device__ __forceinline__ const float *block_src(const float *__restrict__ pcm,
                                                   const vbm_ve_gather &g)
 {
     if (!GATHER) return pcm + blk * n;
-    const long c = blk / g.steps;
-    const int t = (int)(blk - c * g.steps);
-    const int s = (int)(c / g.ch);
+    const int c = (int)blk / g.steps;              // (fewer than 2^31 blocks per launch)
+    const int t = (int)blk - c * g.steps;
+    const int s = c / g.ch;
     const int j = g.first[s] + g.t0 + t;
     if (j >= g.last[s]) return nullptr;
-    return pcm + (long)g.parity[s] * g.plane + c * g.cap + g.base[s] + (long)j * 64;
+    return pcm + (long)g.parity[s] * g.plane + (long)c * g.cap + g.base[s] + (long)j * 64;
 }
 
 // group of eight 16-B loads -> registers
@@ -152,13 +152,33 @@ __device__ __forceinline__ bool issue_loads(float4 (&v)[8], const float *__restr
 {
     using G = Geo<N>;
     bool any = false;
+    // Gathered blocks (the envelope's search MDCTs: 16 blocks of 128 samples per group): where a block starts takes
+    // two integer divisions and four loads of per-stream state; lane b resolves block b once and the eight loads of
+    // a lane pick their block's address up by shuffle (each lane resolving the block of each of its loads spent
+    // more instructions on addresses than the transform has)
+    unsigned alo = 0, ahi = 0;
+    if (GATHER) {
+        const float *mine = nullptr;
+        if (lane < G::BPG) {
+            const long blk = group * G::BPG + lane;
+            if (blk < nblocks) mine = block_src<GATHER>(pcm, blk, N, g);
+        }
+        alo = (unsigned)(unsigned long long)(uintptr_t)mine;
+        ahi = (unsigned)((unsigned long long)(uintptr_t)mine >> 32);
+    }
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         int P = lane + 64 * k;
         int b = P / G::C, p = P % G::C;
         int q0 = (p < G::R2) ? (G::R2 - 1 - p) : (7 * N / 16 - 1 - p);
         long blk = group * G::BPG + b;
-        const float *src = (blk < nblocks) ? block_src<GATHER>(pcm, blk, N, g) : nullptr;
+        const float *src;
+        if (GATHER) {
+            const unsigned lo = (unsigned)__shfl((int)alo, b), hi = (unsigned)__shfl((int)ahi, b);
+            src = reinterpret_cast<const float *>((uintptr_t)(((unsigned long long)hi << 32) | lo));
+        } else {
+            src = (blk < nblocks) ? block_src<GATHER>(pcm, blk, N, g) : nullptr;
+        }
         if (src) {
             v[k] = *reinterpret_cast<const float4 *>(src + 4 * q0);
             any = true;
