@@ -95,9 +95,9 @@ struct vbm_encoder {
     int call_big_w = -1;                   // rounds built on the device: workspace of the current call's big batch
     // ... run as HIP graphs: the ~180 launches of a round cost the host more than the round costs the device, and
     // with device-resident counts every launch of a round has the same arguments each time its workspace comes up.
-    // Three in-order streams: gq[0] all small batches of all rounds, gq[1] the front halves of the big (first round,
-    // long blocks) batches, gq[2] their back halves.  A group = the launches of one of them for one workspace,
-    // captured the second time it is needed and replayed from then on.
+    // Streams: sub[0..3] the small batches of block type 0..3 of all rounds (high priority), sub[4] the front halves of
+    // the big (first round, long blocks) batches, sub[5] their back halves.  A group = the launches of one half of one
+    // batch for one workspace, captured the second time it is needed and replayed from then on.
     struct round_graph { hipGraphExec_t exec = nullptr; int uses = 0; };
     // [workspace][block type; 4 = the big batch (type 3, first round): its launches differ from a small type-3 batch's
     // (throughput variants of the kernels, own streams)][0 whole pipeline, 1 front half, 2 back half]
