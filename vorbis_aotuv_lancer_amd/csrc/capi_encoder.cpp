@@ -704,7 +704,7 @@ extern "C" int vbm_analysis_batch2(vbm_encoder *e, int block_mode, int nsb, cons
     STAGE(1, st, RUN(vbm_launch_window_fft_log(b.pcm, b.logfft_bm, b.local_ampmax, W ? b.wflags_cb : nullptr,
                                                vbm_setup_device_ptrs(e->H)->fft_wa[W], vbm_setup_device_ptrs(e->H)->window[W],
                                                vbm_setup_device_ptrs(e->H)->window[0], b.N, s->blocksizes[0], b.ncb, nullptr, 0, st)));
-    STAGE(2, st, RUN(vbm_launch_transpose_in(&b, st)));
+    // (stage 2, "transpose": gone — k_noisemask writes the tiled MDCT rows itself)
 
     // the stages between the transforms and the hand-over: psychoacoustics, offset_and_mix, block state
     auto front_stages = [&](vbm_batch &v, hipStream_t q, int part) -> int {
@@ -849,7 +849,6 @@ static int enqueue_job(vbm_encoder *e, const type_job &j)
       RUN(vbm_launch_window_fft_log(v.pcm, v.logfft_bm, v.local_ampmax, W ? v.wflags_cb : nullptr,
                                     vbm_setup_device_ptrs(e->H)->fft_wa[W], vbm_setup_device_ptrs(e->H)->window[W],
                                     vbm_setup_device_ptrs(e->H)->window[0], v.N, s->blocksizes[0], v.ncb, v.d_nsb, e->ch, q)); }
-    { TIMED(2, q); RUN(vbm_launch_transpose_in(&v, q)); }
     // the transforms above read the block's PCM only; from here on the carried stream state is involved: the
     // batches this batch's streams were last part of come first (those on this very HIP stream already do)
     if (!j.grouped)

@@ -6,8 +6,9 @@
 // running sums N, X, XX, Y, XY of a block live in LDS (five arrays of n floats: 20 KB for a long block, so several
 // workgroups share a CU); logmdct, work and noise of bin i live in the registers of thread i mod 256, for all NB
 // blocks.  HBM traffic is the algorithmic one: the block's MDCT row in (block-major, straight from k_window_mdct),
-// logmdct / logmask / epeak rows and the npeak entries out (tiled bin-major: the lane-per-block kernels behind
-// this one read them), the carried lastmdct row in for M9.
+// MDCT (the layout change for k_mix and the couple kernels rides along) / logmdct / logmask / epeak rows and the
+// npeak entries out (tiled bin-major: the lane-per-block kernels behind this one read them), the carried lastmdct row
+// in for M9.
 //
 //   terms    every bin's five addends w, w*x, w*x*x, w*y, w*x*y (lib/psy.c:3509-3541) — independent per bin.
 //   scan     the running sums themselves are order-bound float chains (the source adds bin after bin; no other
@@ -270,12 +271,17 @@ __global__ __launch_bounds__(NM_THREADS) void k_noisemask(vbm_batch b, const int
             const int iw = (i < i2) ? i : i2 - 1;
             wlo[r] = 0; whi[r] = 0;
             if (i < n && iw >= 0) { wlo[r] = bark_lo[iw]; whi[r] = bark_hi[iw]; }
+            float mv[NB];
 #pragma unroll
             for (int blk = 0; blk < NB; blk++) {
                 float v = 0.f;
                 if (i < n && blk < nb) v = src[(size_t)blk * n + i];
+                mv[blk] = v;
                 lm[r][blk] = (float)((double)vbm_todB(v) + .345);
             }
+            // the MDCT rows in the tiled layout for the lane-per-block kernels behind this one (k_mix, couple): this
+            // kernel reads the block-major rows anyway, so no transpose pass of its own is needed
+            if (i < n) put_row<NB>(b.mdctT + tile + (size_t)i * 64, mv, nb);
         }
     }
 
