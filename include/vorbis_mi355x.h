@@ -375,6 +375,18 @@ int vbm_window_mdct_time(const vbm_mdct_plan *plan, const float *d_pcm, float *d
                          const uint8_t *d_wflags, long nblocks, int iters, void *stream,
                          float *ms_total);
 
+/* ---- test instrumentation --------------------------------------------------------------------------------
+ * The path is spread over several internal HIP streams; events order them.  These calls make a missing edge show
+ * deterministically (tests/test_ordering_gpu.py); they change timing and scratch contents only, never results.
+ *   vbm_debug_set_delay      a kernel that spins for `usec` microseconds (<= 100000) is put in front of the work at
+ *                            every point of the host code whose bit is set in `mask` (points: csrc/vbm_internal.h,
+ *                            enum vbm_delay_point); process-wide; usec = 0 switches it off
+ *   vbm_debug_poison_workspace  fills the scratch arrays of encoder workspace w (-1: all) with `byte`, device idle
+ *   vbm_debug_poison_frontend   the same for the front end's block buffers, search spectra and round lists */
+int vbm_debug_set_delay(unsigned mask, int usec);
+int vbm_debug_poison_workspace(vbm_encoder *enc, int w, int byte);
+int vbm_debug_poison_frontend(vbm_frontend *fe, int byte);
+
 #ifdef __cplusplus
 }
 #endif

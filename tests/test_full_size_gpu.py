@@ -1,15 +1,31 @@
 """BASELINE configs[2] size on the device: 16384 stereo q5 streams through the front end and the per-block
-path, and configs[4]: 8192 streams of 48 kHz 5.1 q8 (long + short blocks).  Size-independent properties: 16 distinct signals are dealt round-robin over the 16384 streams, so
-every stream must produce exactly the packets of the first stream that carries its signal (any lane / tile /
-batch-position dependence would break this), and those 16 are compared with the oracle."""
+path, and configs[4]: 8192 streams of 48 kHz 5.1 q8 (long + short blocks).  Size-independent properties: K distinct
+signals are dealt round-robin over the streams, so every stream must produce exactly the packets of the first stream
+that carries its signal (any lane / tile / batch-position / scheduling dependence would break this;
+tests/gpuutil.py reports where), and those K are compared with the oracle."""
 import numpy as np
 import pytest
 import torch
 
 from tests import orc
-from tests.signals import synth_signal
+from tests.gpuutil import TwinLedger
+from tests.signals import burst_signal, synth_signal
 
 pytestmark = pytest.mark.gpu
+
+
+def oracle_packets(oracle, osetup, sig, nchunks, finish=False):
+    st = orc.Stream(osetup)
+    oracle.lib.orc_stream_set_capture(st.v, 0)
+    want = []
+    for c in range(nchunks):
+        st.write(sig[:, c * 1024:(c + 1) * 1024])
+        want.extend(b["packet"] for b in st.blocks())
+    if finish:
+        st.finish()
+        want.extend(b["packet"] for b in st.blocks())
+    st.close()
+    return want
 
 
 @pytest.mark.parametrize("S,K,ch,rate,q,nchunks,multi", [
@@ -24,55 +40,90 @@ def test_full_size_from_pcm(oracle, cuda, S, K, ch, rate, q, nchunks, multi):
     setup = v.Setup(ch, rate, q)
     enc = v.Encoder(setup, S)
     fe = v.FrontEnd(enc)
-    first = [[] for _ in range(K)]       # packets of streams 0..K-1
-    nblocks = 0
+    led = TwinLedger(S, K, cuda)
+    rno = 0
     for c in range(nchunks):
         chunk = base[:, :, c * 1024:(c + 1) * 1024].repeat(S // K, 1, 1).contiguous()   # stream s carries signal s % K
         fe.write(chunk)
-        pending = []
         while True:
             if multi:
-                if not pending:
-                    info_all, packets_all, nbytes_all, counts = fe.encode_rounds(min_rounds=64, max_rounds=4)
-                    at = 0
-                    for cnt in counts:
-                        pending.append((info_all[at:at + cnt].copy(), packets_all[at:at + cnt], nbytes_all[at:at + cnt]))
-                        at += cnt
-                    if not pending:
-                        break
-                info, packets, nbytes = pending.pop(0)
+                info_all, packets_all, nbytes_all, counts = fe.encode_rounds(min_rounds=64, max_rounds=4)
+                if not counts:
+                    break
+                at = 0
+                for cnt in counts:
+                    led.add_host_round(info_all[at:at + cnt].copy(), packets_all[at:at + cnt], nbytes_all[at:at + cnt],
+                                       f"write {c} round {rno}")
+                    at += cnt
+                    rno += 1
             else:
                 info, packets, nbytes = fe.encode_round()
                 if len(info) == 0:
                     break
-            nblocks += len(info)
-            # compare on the device: every packet against the packet of stream (s % K) of the same round
-            stream = torch.from_numpy(np.ascontiguousarray(info["stream"])).to(cuda).long()
-            pos_of = torch.full((S,), -1, dtype=torch.long, device=cuda)
-            pos_of[stream] = torch.arange(len(info), device=cuda)
-            ref_pos = pos_of[stream % K]
-            assert bool((ref_pos >= 0).all()), "a stream produced a block in a round in which its twin did not"
-            assert bool((nbytes == nbytes[ref_pos]).all())
-            assert bool((nbytes >= 0).all()), "packet buffer overflow"
-            # bytes beyond a packet's length are zero (the packet words are cleared first), so whole rows compare
-            assert bool((packets == packets[ref_pos]).all()), "identical input, different packets"
-            for k in range(K):
-                p = int(pos_of[k])
-                if p >= 0:
-                    first[k].append(bytes(packets[p, :int(nbytes[p])].cpu().numpy()))
-    assert nblocks >= S * (nchunks - 3)
+                led.add_host_round(info, packets, nbytes, f"write {c} round {rno}")
+                rno += 1
+    led.finish("all rounds")
+    assert led.nblocks >= S * (nchunks - 3)
     if ch == 6:
-        assert nblocks > S * nchunks            # short blocks occurred
+        assert led.nblocks > S * nchunks            # short blocks occurred
     osetup = orc.Setup(oracle, ch, rate, q)
     for k in range(K):
-        st = orc.Stream(osetup)
-        oracle.lib.orc_stream_set_capture(st.v, 0)
-        want = []
-        for c in range(nchunks):
-            st.write(sigs[k][:, c * 1024:(c + 1) * 1024])
-            want.extend(b["packet"] for b in st.blocks())
-        st.close()
-        assert first[k] == want, f"signal {k}: packets differ from the oracle"
+        assert led.lead_packets(k) == oracle_packets(oracle, osetup, sigs[k], nchunks), f"signal {k}: packets differ from the oracle"
+    fe.close()
+    enc.close()
+
+
+def test_full_size_benchmarked_path(oracle, cuda, monkeypatch):
+    """The path bench.py times, at its size: 16384 stereo q5 streams, rounds built on the device replayed as HIP graphs,
+    four workspaces, 2, 1, 1 rounds per 1024-sample write, the feeding stream never tied to the outputs (lazy = 2, a
+    consumer stream joins; the first six writes run three rounds each, as the bench's warm-up does, to clear the start of
+    the streams where all of them deliver short blocks at once), 64 writes of signals with a noise burst every 40000
+    samples (a fifth of the blocks are short ones).  Every stream against its twin (sequence check: a stream may be put off to a later round than its
+    twin), the 16 distinct signals against the oracle, end of stream included."""
+    import vorbis_aotuv_lancer_amd as v
+    monkeypatch.setenv("VBM_WORKSPACES", "4")
+    S, K, ch, rate, q, nchunks = 16384, 16, 2, 44100, 0.5, 64
+    sigs = [burst_signal(ch, rate, nchunks * 1024, seed=400 + k, period=40000, level=1.0 if k % 5 else 0.05) for k in range(K)]
+    base = torch.from_numpy(np.stack(sigs)).to(cuda)
+    setup = v.Setup(ch, rate, q)
+    lanes = v.lib.vbm_device_round_lanes(setup._h, S)
+    enc = v.Encoder(setup, S, max_batch=lanes)
+    fe = v.FrontEnd(enc)
+    led = TwinLedger(S, K, cuda)
+    consumer = torch.cuda.Stream(device=cuda)
+    pattern = (2, 1, 1)
+    for c in range(nchunks):
+        chunk = base[:, :, c * 1024:(c + 1) * 1024].repeat(S // K, 1, 1).contiguous()
+        fe.write(chunk)
+        info, packets, nbytes, counts = fe.encode_rounds_device(nrounds=3 if c < 6 else pattern[c % 3], lazy=2)
+        fe.join(consumer)
+        with torch.cuda.stream(consumer):
+            led.add_device_rounds(info, packets, nbytes, f"write {c}")
+        consumer.synchronize()          # (the ledger's temporaries go back to torch's allocator on the consumer stream)
+    modes, samples = fe.device_stats()
+    assert fe.refused_writes == 0
+    assert sum(modes) == led.nblocks
+    assert modes[0] + modes[1] >= 0.10 * sum(modes), modes        # block switching happened
+    # host-built rounds drain what is left and end the streams
+    torch.cuda.synchronize()
+    while True:
+        info, packets, nbytes = fe.encode_round()
+        if len(info) == 0:
+            break
+        led.add_host_round(info, packets, nbytes, "drain")
+    fe.finish()
+    while True:
+        info, packets, nbytes = fe.encode_round()
+        if len(info) == 0:
+            break
+        led.add_host_round(info, packets, nbytes, "end of stream")
+    led.finish("benchmarked path")
+    osetup = orc.Setup(oracle, ch, rate, q)
+    for k in range(K):
+        assert led.lead_packets(k) == oracle_packets(oracle, osetup, sigs[k], nchunks, finish=True), \
+            f"signal {k}: packets differ from the oracle"
+    fe.close()
+    enc.close()
 
 
 def test_16384_streams_two_stream_form_is_deterministic(cuda):

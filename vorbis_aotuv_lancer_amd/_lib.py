@@ -99,6 +99,9 @@ SIGNATURES = {
     "vbm_host_mdct_trig": (C.c_int, [C.c_int, C.c_void_p]),
     "vbm_host_fft_twiddles": (C.c_int, [C.c_int, C.c_void_p]),
     "vbm_host_book_lattice": (C.c_int, [C.c_long, C.c_long, C.c_long, C.c_int, C.POINTER(C.c_int)]),
+    "vbm_debug_set_delay": (C.c_int, [C.c_uint, C.c_int]),
+    "vbm_debug_poison_workspace": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "vbm_debug_poison_frontend": (C.c_int, [C.c_void_p, C.c_int]),
     "vbm_window_mdct_time": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int,
                                        C.c_void_p, C.POINTER(C.c_float)]),
 }

@@ -34,6 +34,8 @@ struct vbm_encoder {
     int max_packet_bytes;
     int max_oct, max_partvals;
     std::vector<void *> allocs;
+    std::vector<size_t> alloc_bytes;          // size of every entry of `allocs`
+    size_t ws_alloc[kMaxWS + 1] = {};         // allocs [ws_alloc[w], ws_alloc[w + 1]) are the scratch of workspace w (vbm_debug_poison_workspace)
     // Two complete batch workspaces (device pointers; the stream state is shared).  Consecutive calls
     // alternate between them, so that vbm_analysis_batch2 can run the second half of call k (floor fit,
     // couple/quantise, packet assembly) on one HIP stream while the first half of call k+1 (transforms,
@@ -153,6 +155,7 @@ static int dalloc(vbm_encoder *e, T **p, size_t count, bool zero = true)
     hipError_t err = hipMalloc((void **)p, count * sizeof(T) + 256);
     if (err != hipSuccess) return vbm_set_hip_error(err, "hipMalloc(encoder workspace)");
     e->allocs.push_back(*p);
+    e->alloc_bytes.push_back(count * sizeof(T) + 256);
     if (zero) {
         err = hipMemset(*p, 0, count * sizeof(T) + 256);
         if (err != hipSuccess) return vbm_set_hip_error(err, "hipMemset");
@@ -291,6 +294,7 @@ extern "C" int vbm_encoder_create(vbm_encoder **out, vbm_setup_handle *setup, in
   }
   for (int w = 0; w < e->nws; w++) {
     vbm_batch &b = e->bw[w];
+    e->ws_alloc[w] = e->allocs.size();
     if (w) {
         memset(&b, 0, sizeof(b));
         b.setup = e->bw[0].setup;
@@ -362,6 +366,7 @@ extern "C" int vbm_encoder_create(vbm_encoder **out, vbm_setup_handle *setup, in
     A(b.packet_bits, int, Ls);
     b.stream_id = e->d_stream_id[w];
     b.wflags = e->d_wflags[w];
+    e->ws_alloc[w + 1] = e->allocs.size();
   }
 #undef A
     for (int i = 0; i < kMaxWS; i++)
@@ -399,6 +404,8 @@ extern "C" int vbm_encoder_create(vbm_encoder **out, vbm_setup_handle *setup, in
         env = getenv("VBM_OVERLAP_BRANCHES");
         if (env) e->overlap_branches = atoi(env) != 0;
     }
+    // the zero fills above went to the null stream, which the internal (non-blocking) HIP streams do not wait for
+    if (hipDeviceSynchronize() != hipSuccess) { vbm_encoder_destroy(e); return VBM_EHIP; }
     *out = e;
     return VBM_OK;
 }
@@ -696,6 +703,7 @@ extern "C" int vbm_analysis_batch2(vbm_encoder *e, int block_mode, int nsb, cons
             e->spans.push_back({(k), eb_, ee_});                                               \
         }                                                                                      \
     } while (0)
+    vbm_debug_delay_point(VBM_DP_BATCH_FRONT, st);
     RUN(vbm_launch_spread_flags(&b, st));
     // loop A: window + MDCT, window + FFT + log spectrum (wave per block), whole batch
     STAGE(0, st, RUN(vbm_launch_window_mdct(b.pcm, b.mdct_bm, W ? b.wflags_cb : nullptr,
@@ -766,6 +774,7 @@ extern "C" int vbm_analysis_batch2(vbm_encoder *e, int block_mode, int nsb, cons
             if (sb1 <= sb0) continue;
             hipStream_t qb = part ? e->sub[part] : sback;
             if ((err = hipStreamWaitEvent(qb, e->ev_front[w], 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
+            vbm_debug_delay_point(VBM_DP_BATCH_BACK, qb);
             vbm_batch vs = nback > 1 ? slice_of(b, sb0, sb1 - sb0) : b;
             if ((rc = back_stages(vs, qb, sb0))) return rc;
             if (part) {
@@ -829,6 +838,7 @@ static int enqueue_job(vbm_encoder *e, const type_job &j)
     hipStream_t q = j.grouped ? j.q_on : (j.big ? e->sub[4] : e->sub[m]);
     const int qid = j.big ? 4 : m;
     if (!j.grouped && (err = hipStreamWaitEvent(q, e->ev_fork, 0)) != hipSuccess) return vbm_set_hip_error(err, "hipStreamWaitEvent");
+    if (!j.grouped && j.part != 2) vbm_debug_delay_point(j.big ? VBM_DP_JOB_BIG : VBM_DP_JOB_SMALL, q);
     vbm_batch full;
     configure(e, full, m, j.bound, j.pcm, w);
     vbm_batch v = slice_of(full, j.lane0, j.bound);
@@ -857,6 +867,7 @@ static int enqueue_job(vbm_encoder *e, const type_job &j)
             if (((j.depmask >> (ww * 4 + t)) & 1u) && (e->slot_queue[ww][t] != qid || s->managed) &&
                 (err = hipStreamWaitEvent(q, s->managed ? e->ev_done[ww][t] : e->ev_state[ww][t], 0)) != hipSuccess)
                 return vbm_set_hip_error(err, "hipStreamWaitEvent");
+    if (!j.grouped) vbm_debug_delay_point(VBM_DP_JOB_STATE, q);
     { TIMED(3, q); RUN(vbm_launch_prologue(&v, q)); }
     { TIMED(4, q); RUN(vbm_launch_noisemask(&v, q)); }
     { TIMED(5, q); RUN(vbm_launch_tonemask(&v, s->psy[v.block_mode].total_octave_lines, q)); }
@@ -872,6 +883,7 @@ static int enqueue_job(vbm_encoder *e, const type_job &j)
             return vbm_set_hip_error(err, "big batch hand-over");
         q = e->sub[5];
     }
+    vbm_debug_delay_point(VBM_DP_JOB_BACK, q);
     }
     if (s->managed) {
         TIMED(10, q);
@@ -883,6 +895,7 @@ static int enqueue_job(vbm_encoder *e, const type_job &j)
         { TIMED(10, q); RUN(vbm_launch_pack(&v, q)); }
     }
     if (j.grouped) return VBM_OK;     // the group's caller copies the outputs and records the events
+    vbm_debug_delay_point(VBM_DP_JOB_OUT, q);
     { TIMED(11, q);
       if (j.d_packets && !s->managed)
           RUN(vbm_launch_untranspose_counted((const int *)v.packetT, (int *)j.d_packets, e->max_packet_bytes / 4,
@@ -1151,7 +1164,9 @@ int vbm_encoder_device_round_open(vbm_encoder *e, hipStream_t fork, int *w_out, 
     if (!e->d_counts_ws) {
         if (hipMalloc((void **)&e->d_counts_ws, kMaxWS * 4 * sizeof(int)) != hipSuccess) return VBM_EHIP;
         e->allocs.push_back(e->d_counts_ws);
-        (void)hipMemset(e->d_counts_ws, 0, kMaxWS * 4 * sizeof(int));
+        e->alloc_bytes.push_back(kMaxWS * 4 * sizeof(int));
+        // (null-stream fill: the front end's non-blocking stream would not wait for it)
+        if (hipMemset(e->d_counts_ws, 0, kMaxWS * 4 * sizeof(int)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return VBM_EHIP;
     }
     *w_out = w;
     *d_stream_id = e->d_stream_id[w];
@@ -1259,12 +1274,15 @@ static int device_round_run_graphs(vbm_encoder *e, int w, const int *lane0, cons
         if ((rc = wait_preds(qF, 3, 4))) return rc;
         type_job jf = job_of(3, 1), jb = job_of(3, 2);
         vbm_debug_stamp(qF, 10);
+        vbm_debug_delay_point(VBM_DP_DEV_BIG_FRONT, qF);
         if ((rc = run_group(e, e->gJ[w][4][1], qF, &jf, 1, 1))) return rc;
         vbm_debug_stamp(qF, 11);
         if ((err = hipEventRecord(e->ev_state_big[w], qF)) != hipSuccess ||
             (err = hipStreamWaitEvent(qB, e->ev_state_big[w], 0)) != hipSuccess) return vbm_set_hip_error(err, "big batch hand-over");
         vbm_debug_stamp(qB, 12);
+        vbm_debug_delay_point(VBM_DP_DEV_BIG_BACK, qB);
         if ((rc = run_group(e, e->gJ[w][4][2], qB, &jb, 1, 2))) return rc;
+        vbm_debug_delay_point(VBM_DP_DEV_OUT, qB);
         if ((rc = copy_outputs(e, jb, qB))) return rc;
         vbm_debug_stamp(qB, 13);
         if ((err = hipEventRecord(e->ev_done[w][3], qB)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
@@ -1284,9 +1302,12 @@ static int device_round_run_graphs(vbm_encoder *e, int w, const int *lane0, cons
         type_job j = job_of(m, 1), j2 = job_of(m, 2);
         j.few = j2.few = 1;
         vbm_debug_stamp(q, 20 + m);
+        vbm_debug_delay_point(VBM_DP_DEV_SMALL_FRONT, q);
         if ((rc = run_group(e, e->gJ[w][m][1], q, &j, 1, 0))) return rc;
         if ((err = hipEventRecord(e->ev_state[w][m], q)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
+        vbm_debug_delay_point(VBM_DP_DEV_SMALL_BACK, q);
         if ((rc = run_group(e, e->gJ[w][m][2], q, &j2, 1, 0))) return rc;
+        vbm_debug_delay_point(VBM_DP_DEV_OUT, q);
         if ((rc = copy_outputs(e, j2, q))) return rc;
         vbm_debug_stamp(q, 30 + m);
         if ((err = hipEventRecord(e->ev_done[w][m], q)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
@@ -1448,6 +1469,24 @@ extern "C" int vbm_analysis_round_wait_workspace(vbm_encoder *e, void *stream)
             e->reuse_pending[w][m] = false;
         }
     return VBM_OK;
+}
+
+// Test instrumentation: every scratch array of workspace w (-1: all) is filled with `byte` while the device is idle.
+// A batch writes what it reads, so its packets do not depend on what the workspace held before (tests/test_ordering_gpu.py).
+extern "C" int vbm_debug_poison_workspace(vbm_encoder *e, int w, int byte)
+{
+    if (!e || w >= e->nws) return VBM_EINVAL;
+    hipError_t err = hipDeviceSynchronize();
+    if (err != hipSuccess) return vbm_set_hip_error(err, "hipDeviceSynchronize");
+    for (int ww = 0; ww < e->nws; ww++) {
+        if (w >= 0 && ww != w) continue;
+        for (size_t k = e->ws_alloc[ww]; k < e->ws_alloc[ww + 1]; k++)
+            if ((err = hipMemset(e->allocs[k], byte, e->alloc_bytes[k])) != hipSuccess) return vbm_set_hip_error(err, "hipMemset(poison)");
+        e->last_ids[ww].clear();        // (the id / flag lists of the workspace are gone too: upload them again)
+        e->last_flags[ww].clear();
+    }
+    err = hipDeviceSynchronize();
+    return err == hipSuccess ? VBM_OK : vbm_set_hip_error(err, "hipDeviceSynchronize");
 }
 
 extern "C" int vbm_encoder_profile_begin(vbm_encoder *e, int max_calls)

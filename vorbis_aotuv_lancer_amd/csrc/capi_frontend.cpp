@@ -283,6 +283,7 @@ extern "C" int vbm_frontend_write(vbm_frontend *fe, const float *d_pcm, int vals
         if (rc) return rc;
     }
     vbm_debug_stamp(st, 0);
+    vbm_debug_delay_point(VBM_DP_FE_WRITE, st);
     if (vbm_fe_launch_append(&fe->f, d_pcm, vals, s->pre_amplitude, st)) return VBM_EHIP;
     {   // the caller's buffer is free again once the append has run
         int rc = fe_leave(fe, stream);
@@ -528,12 +529,14 @@ static int round_impl(vbm_frontend *fe, uint8_t *d_packets, int *d_packet_bytes,
         if (vbm_fe_launch_gather(&fe->f, fe->d_ids + offset[m], fe->d_begin + offset[m], count[m], N, blocks, nullptr, st))
             return VBM_EHIP;
     }
+    vbm_debug_delay_point(VBM_DP_FE_FORK, st);
     {
         // the batches are forked from the front end's stream (behind the gather); the caller's stream joins them
         int rc = vbm_analysis_round_begin(fe->enc, count, fe->h_ids, fe->h_flags, round_blocks, d_packets, d_packet_bytes, fq);
         if (rc) return rc;
         if (!defer && (rc = vbm_analysis_round_join(fe->enc, stream))) return rc;
     }
+    vbm_debug_delay_point(VBM_DP_FE_SHIFT, st);
     if (vbm_fe_launch_shift(&fe->f, fe->d_dec, st)) return VBM_EHIP;
     *nblocks = total;
     return VBM_OK;
@@ -712,6 +715,9 @@ extern "C" int vbm_frontend_encode_rounds_device(vbm_frontend *fe, int nrounds, 
         A(fe->d_stats, unsigned long long, 8);
         A(fe->d_blocks_dev, float, (size_t)fe->nblocks_bufs * L * ch * bs1);
 #undef A
+        // the zero fills went to the null stream; the front end's own stream is non-blocking and would run on beside
+        // them (the first round's gather writing blocks that the fill then wipes): wait here, once
+        if ((err = hipDeviceSynchronize()) != hipSuccess) return vbm_set_hip_error(err, "hipDeviceSynchronize");
     }
     // evaluate the envelope over everything written since the last round (_ve_envelope_search, first part)
     if (fe->dirty) {
@@ -762,6 +768,7 @@ extern "C" int vbm_frontend_encode_rounds_device(vbm_frontend *fe, int nrounds, 
         R.begin = fe->d_begin_lane;
         R.info = d_info + (size_t)r * fe->lanes;
         R.stats = fe->d_stats;
+        vbm_debug_delay_point(VBM_DP_DEV_PLAN, q);
         if (vbm_fe_launch_round_plan(&fe->f, ds, &R, fe->d_type, fe->d_dec, bytes_r, fe->lanes, q)) return VBM_EHIP;
         if ((err = hipMemcpyAsync(counts_r, counts_ws, 4 * sizeof(int), hipMemcpyDeviceToDevice, q)) != hipSuccess)
             return vbm_set_hip_error(err, "hipMemcpyAsync(counts)");
@@ -776,6 +783,7 @@ extern "C" int vbm_frontend_encode_rounds_device(vbm_frontend *fe, int nrounds, 
         rc = vbm_encoder_device_round_run(fe->enc, w, fe->lane0, caps, counts_ws, blocks,
                                           d_packets ? d_packets + (size_t)r * fe->lanes * maxb : nullptr, bytes_r, r == 0, q);
         if (rc) return rc;
+        vbm_debug_delay_point(VBM_DP_FE_SHIFT, q);
         if (vbm_fe_launch_shift(&fe->f, fe->d_dec, q)) return VBM_EHIP;
     }
     vbm_debug_stamp(q, 4);
@@ -799,6 +807,25 @@ extern "C" int vbm_frontend_device_stats(vbm_frontend *fe, unsigned long long *o
     if ((err = hipMemcpy(out, fe->d_stats, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost)) != hipSuccess)
         return vbm_set_hip_error(err, "hipMemcpy(stats)");
     return VBM_OK;
+}
+
+// Test instrumentation: the front end's pure scratch (block buffers of the rounds, search spectra, round lists) is
+// filled with `byte` while the device is idle; nothing a later call reads may come from there.
+extern "C" int vbm_debug_poison_frontend(vbm_frontend *fe, int byte)
+{
+    if (!fe) return VBM_EINVAL;
+    hipError_t err = hipDeviceSynchronize();
+    if (err != hipSuccess) return vbm_set_hip_error(err, "hipDeviceSynchronize");
+    const size_t SC = (size_t)fe->S * fe->ch, bs1 = (size_t)fe->hs->blocksizes[1];
+    if ((err = hipMemset(fe->d_blocks, byte, (size_t)fe->nblocks_bufs * SC * bs1 * sizeof(float))) != hipSuccess ||
+        (err = hipMemset(fe->f.ve_spec, byte, SC * VBM_FE_CHUNK * 64 * sizeof(float))) != hipSuccess ||
+        (err = hipMemset(fe->d_ids, byte, (size_t)fe->S * sizeof(int))) != hipSuccess ||
+        (err = hipMemset(fe->d_begin, byte, (size_t)fe->S * sizeof(int))) != hipSuccess ||
+        (fe->d_blocks_dev && (err = hipMemset(fe->d_blocks_dev, byte, (size_t)fe->nblocks_bufs * fe->lanes * fe->ch * bs1 * sizeof(float))) != hipSuccess) ||
+        (fe->d_begin_lane && (err = hipMemset(fe->d_begin_lane, byte, (size_t)fe->lanes * sizeof(int))) != hipSuccess))
+        return vbm_set_hip_error(err, "hipMemset(poison)");
+    err = hipDeviceSynchronize();
+    return err == hipSuccess ? VBM_OK : vbm_set_hip_error(err, "hipDeviceSynchronize");
 }
 
 extern "C" int vbm_frontend_join(vbm_frontend *fe, void *stream)

@@ -645,12 +645,11 @@ static inline dim3 grid_for(int lanes) { return dim3((unsigned)((lanes + 63) / 6
 
 extern "C" int vbm_launch_floor_fit(const vbm_batch *b, hipStream_t st)
 {
-    static int lpw = 0;
-    if (!lpw) {
+    static const int lpw = [] {
         const char *e = getenv("VBM_FLOORFIT_LPW");   // tuning knob: lanes per wavefront of the greedy fit
-        lpw = e ? atoi(e) : 64;
-        if (lpw < 1 || lpw > 64) lpw = 64;
-    }
+        const int v = e ? atoi(e) : 64;
+        return (v < 1 || v > 64) ? 64 : v;
+    }();
     if (!b->mix_makes_qf)   // otherwise k_mix has written qf_bm already (psy_kernels.hip)
         hipLaunchKernelGGL(k_floor_prep, dim3((unsigned)((b->ncb + 63) / 64), (unsigned)((b->n + 63) / 64)), dim3(256), 0,
                            st, *b);
@@ -663,14 +662,10 @@ extern "C" int vbm_launch_floor_fit(const vbm_batch *b, hipStream_t st)
     // pipeline, where its 18 KB of LDS per wavefront keep the other half's kernels off the CUs; the per-block chain
     // of ~27 greedy steps, each a handful of dependent reads and a double-precision solve, is what bounds either.)
     size_t lds = (size_t)(b->fit_max_posts - 1) * 10 * 64 * sizeof(int);
-    static int force = -1;
-    if (force < 0) force = getenv("VBM_FLOORFIT_LDS") ? 1 : 0;
-    static bool allowed = false;
-    if (!allowed) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_floor_fit<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  80 * 1024);
-        allowed = true;
-    }
+    static const int force = getenv("VBM_FLOORFIT_LDS") ? 1 : 0;
+    static const bool allowed = hipFuncSetAttribute(reinterpret_cast<const void *>(k_floor_fit<true>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess;
+    (void)allowed;
     if (lds <= 80 * 1024 && lpw == 64 && (force || b->few || b->ncb <= 64 * 64) && !getenv("VBM_FLOORFIT_PRIVATE"))
         hipLaunchKernelGGL(k_floor_fit<true>, dim3((unsigned)((b->ncb + 63) / 64)), dim3(64), lds, st, *b, 64);
     else

@@ -540,16 +540,13 @@ __global__ __launch_bounds__(NM_THREADS) void k_noisemask(vbm_batch b, const int
 template <int NB, int ROWS>
 int launch(const vbm_batch *b, hipStream_t st)
 {
-    static int phases = -1;
-    if (phases < 0) phases = getenv("VBM_NOISE_PHASES") ? atoi(getenv("VBM_NOISE_PHASES")) : 31;   // timing experiments
+    // (called from several host threads at once: one-time set-up through initialisers of function-local statics)
+    static const int phases = getenv("VBM_NOISE_PHASES") ? atoi(getenv("VBM_NOISE_PHASES")) : 31;   // timing experiments
     size_t lds = (size_t)5 * NB * (b->n + NM_PAD) * sizeof(float);
     if (getenv("VBM_NOISE_LDS_PAD")) lds += (size_t)atoi(getenv("VBM_NOISE_LDS_PAD")) * 1024;   // occupancy experiments
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_noisemask<NB, ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  96 * 1024);
-        attr = true;
-    }
+    static const bool attr = hipFuncSetAttribute(reinterpret_cast<const void *>(k_noisemask<NB, ROWS>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
+    (void)attr;
     const unsigned wgs = (unsigned)((b->ncb + NB - 1) / NB);
     hipLaunchKernelGGL((k_noisemask<NB, ROWS>), dim3((wgs + 7u) & ~7u), dim3(NM_THREADS), lds, st, *b, phases);
     return hipGetLastError() == hipSuccess ? 0 : -2;

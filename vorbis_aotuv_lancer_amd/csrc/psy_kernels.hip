@@ -784,12 +784,11 @@ static inline dim3 grid_for(int lanes) { return dim3((unsigned)((lanes + 63) / 6
 // slices of the bin range for the kernels whose bins are independent (long blocks: 64 bins each)
 static inline int bin_chunks(const vbm_batch *b)
 {
-    static int big = 0;
-    if (!big) {
+    static const int big = [] {
         const char *e = getenv("VBM_BIN_CHUNKS");   // tuning knob: slices of the long-block bin range
-        big = e ? atoi(e) : 16;
-        if (big < 1 || big > 64) big = 16;
-    }
+        const int v = e ? atoi(e) : 16;
+        return (v < 1 || v > 64) ? 16 : v;
+    }();
     const int chunks = b->n >= 1024 ? big : b->n >= 512 ? 8 : b->n >= 256 ? 4 : 2;
     // A small batch (the short rounds of the front end: a few wavefronts on an empty chip) is bound by the
     // latency of each wavefront's walk over its bins, not by throughput: slices of 8-16 bins instead of 64.
@@ -817,13 +816,15 @@ static void allow_big_lds(K kernel)
 }
 static void mix_m0_setup()
 {
-    static bool done = false;
-    if (done) return;
-    allow_big_lds(k_mix<1, false, false, true>);
-    allow_big_lds(k_mix<1, true, false, true>);
-    allow_big_lds(k_mix<2, true, false, true>);
-    allow_big_lds(k_mix<0, true, false, true>);
-    done = true;
+    // (once, whichever host thread comes first: the initialiser of a function-local static)
+    static const bool done = [] {
+        allow_big_lds(k_mix<1, false, false, true>);
+        allow_big_lds(k_mix<1, true, false, true>);
+        allow_big_lds(k_mix<2, true, false, true>);
+        allow_big_lds(k_mix<0, true, false, true>);
+        return true;
+    }();
+    (void)done;
 }
 
 extern "C" int vbm_launch_mix(const vbm_batch *b, hipStream_t st)

@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <mutex>
 #include "batch.h"
 #include "kernels.h"
 
@@ -327,17 +328,22 @@ __global__ __launch_bounds__(TM_NB * 32) void k_tonemask(vbm_batch b, const int 
 template <int NB>
 int launch(const vbm_batch *b, int tn, size_t lds, int phases, hipStream_t st)
 {
-    static int runin = -1;
-    if (runin < 0) {
-        runin = getenv("VBM_TONE_RUNIN") ? atoi(getenv("VBM_TONE_RUNIN")) : 16;
-        runin = (runin + 3) & ~3;
-        if (runin < 8 || runin > 64) runin = 16;
-    }
-    static size_t allowed = 0;
-    if (lds > allowed) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_tonemask<NB>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess) return -2;
-        allowed = lds;
+    // (launchers are called from several host threads at once — one per block type of a round: one-time set-up goes
+    // through initialisers of function-local statics, which C++ runs once, and the LDS limit only ever grows)
+    static const int runin = [] {
+        int r = getenv("VBM_TONE_RUNIN") ? atoi(getenv("VBM_TONE_RUNIN")) : 16;
+        r = (r + 3) & ~3;
+        return (r < 8 || r > 64) ? 16 : r;
+    }();
+    {
+        static std::mutex mu;
+        static size_t allowed = 0;
+        std::lock_guard<std::mutex> guard(mu);
+        if (lds > allowed) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_tonemask<NB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds) != hipSuccess) return -2;
+            allowed = lds;
+        }
     }
     hipLaunchKernelGGL(k_tonemask<NB>, dim3((unsigned)((b->ncb + NB - 1) / NB)), dim3(NB * 32), lds, st, *b, phases, runin);
     return hipGetLastError() == hipSuccess ? 0 : -2;
@@ -351,13 +357,11 @@ size_t lds_bytes(int nb, int tn) { return (size_t)(nb * (tn | 1)) * 4 + (size_t)
 extern "C" int vbm_launch_tonemask(const vbm_batch *b, int tn, hipStream_t st)
 {
     if (tn > TM_CHUNKS * 64 || tn < 2) return -2;
-    static int phases = -1;
-    if (phases < 0) phases = getenv("VBM_TONE_PHASES") ? atoi(getenv("VBM_TONE_PHASES")) : 31;
+    static const int phases = getenv("VBM_TONE_PHASES") ? atoi(getenv("VBM_TONE_PHASES")) : 31;
     // 8 blocks per workgroup (256 threads, ~38 KB of LDS).  Measured on MI355X, 16384 stereo streams: alone the kernel
     // takes the same 0.7 ms with 8, 16 or 32 blocks per workgroup, but beside the noise-mask branch and the previous
     // step's back half (MDCT, couple and residue-VQ workgroups want LDS too) the step takes 3.07 / 3.19 / 3.22 ms.
-    static int force = -1;
-    if (force < 0) force = getenv("VBM_TONE_NB") ? atoi(getenv("VBM_TONE_NB")) : 8;
+    static const int force = getenv("VBM_TONE_NB") ? atoi(getenv("VBM_TONE_NB")) : 8;
     if (force == 16) return launch<16>(b, tn, lds_bytes(16, tn), phases, st);
     return launch<8>(b, tn, lds_bytes(8, tn), phases, st);
 }

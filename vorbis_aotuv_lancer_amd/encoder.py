@@ -119,6 +119,10 @@ class Encoder:
         check(lib.vbm_encoder_fetch_blob(self._h, k, packets.data_ptr(), nbytes.data_ptr(), st), "vbm_encoder_fetch_blob")
         return packets, nbytes
 
+    def debug_poison(self, w=-1, byte=0xFF):
+        """test instrumentation: fill the scratch arrays of workspace w (-1: all) with `byte` (device idle)"""
+        check(lib.vbm_debug_poison_workspace(self._h, w, byte), "vbm_debug_poison_workspace")
+
     def set_sub_batches(self, n):
         """Slices of a batch that run on separate internal HIP streams after the transforms."""
         check(lib.vbm_encoder_set_sub_batches(self._h, n), "vbm_encoder_set_sub_batches")
@@ -296,6 +300,10 @@ class FrontEnd:
                                                     counts.data_ptr(), int(lazy), st),
               "vbm_frontend_encode_rounds_device")
         return info, packets, nbytes, counts
+
+    def debug_poison(self, byte=0xFF):
+        """test instrumentation: fill the front end's scratch (block buffers, search spectra, round lists) with `byte`"""
+        check(lib.vbm_debug_poison_frontend(self._h, byte), "vbm_debug_poison_frontend")
 
     def device_stats(self):
         """running totals of the device-built rounds: ([blocks of type 0..3], samples all streams advanced by)"""
