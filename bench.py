@@ -13,8 +13,12 @@ in HBM) through the device front end — PCM intake, envelope search, block swit
 (vbm_frontend_*) — and the blocks that come out go through the whole per-block path (window, MDCT, FFT, psy,
 floor fit/encode, couple/quantise, residue VQ, packet assembly).  The signal is SURVEY.md §8(d)'s: two sines +
 noise + a 200-sample burst every ~1.33 s at a per-stream phase, so ~15 % of the blocks are short ones.
-value = audio seconds ENCODED inside the timed region (summed over the blocks that came out) / wall seconds
-= concurrent streams encodable at 1x realtime.  The per-block path alone (pre-cut long blocks, no front end: the
+value = audio seconds WRITTEN inside the timed region / wall seconds = concurrent streams encodable at 1x realtime — or
+the audio seconds of the blocks that came out if that is less (streams falling behind their input would otherwise
+count as served); the ratio of the two is reported.  Before the W warm-up steps the streams are started up (PRIME
+writes, the first ten with four rounds each, part of the set-up like loading a model: every stream begins with short
+blocks, which would otherwise leave a backlog of rounds for the timed region to drain, and one burst period has to pass
+before as many streams are catching up after a burst as in the steady state).  The per-block path alone (pre-cut long blocks, no front end: the
 §8(a) measurement) is timed in the same run and reported as `per_block_path`.
 
 Streams shard across ranks with no data-path collective: weak scaling, every rank encodes its own
@@ -69,6 +73,17 @@ STAGE_BYTES = {
 }
 
 
+# kernels behind every stage name (csrc/capi_encoder.cpp: kStageNames), as rocprofv3 lists them
+STAGE_KERNELS = {
+    "window_mdct": ["k_window_mdct<2048>"], "window_fft_log": ["k_window_fft_log<2048>"], "prologue": ["k_prologue"],
+    "noisemask": ["k_noisemask<2,4>"], "tonemask": ["k_tonemask<8>"], "offset_and_mix": ["k_mix<1,false,true,false>", "k_block_state"],
+    "floor_fit": ["k_floor_fit"], "floor_encode": ["k_floor_encode", "k_floor_render"],
+    "couple_quantize": ["k_couple_m6stats", "k_couple_fast<1>"],
+    "pack": ["k_zero_u128", "k_pack_head", "k_nonzero_propagate", "k_res_vq", "k_res_offsets", "k_res_emit"],
+    "packet_out": ["k_from_tiled<int>"],
+}
+
+
 def stream_params(torch, dev, lo, hi):
     """per-stream signal parameters, a function of the GLOBAL stream index only (a stream sounds the same whichever
     rank encodes it)"""
@@ -76,7 +91,8 @@ def stream_params(torch, dev, lo, hi):
     total = hi                                        # draw for [0, hi), keep [lo, hi): index-stable
     f1 = (110.0 + 1650.0 * torch.rand(total, generator=g))[lo:hi]
     f2 = (2000.0 + 4000.0 * torch.rand(total, generator=g))[lo:hi]
-    phase = torch.randint(0, RATE // 3, (total,), generator=g)[lo:hi]
+    # burst phase uniform over the whole 4/3-s period: any window of the run sees the same ~15 % short blocks
+    phase = torch.randint(0, 4 * (RATE // 3), (total,), generator=g)[lo:hi]
     return (f1.view(-1, 1, 1).to(dev), f2.view(-1, 1, 1).to(dev), phase.view(-1, 1, 1).to(dev))
 
 
@@ -174,7 +190,7 @@ def main():
     ap.add_argument("--per-block", action="store_true",
                     help="value = the per-block path alone on pre-cut long blocks (the §8(a) measurement; no front "
                          "end, no block switching) — for A/B work on the kernels")
-    ap.add_argument("--only", choices=["pcm", "block"], default=None, help="run one leg only")
+    ap.add_argument("--only", choices=["pcm", "block", "solo"], default=None, help="run one leg only")
     ap.add_argument("--bitrate", type=int, default=0,
                     help="managed-bitrate setup of this nominal rate (vorbis_encode_init, SURVEY 8f N2: all 15 "
                          "packetblobs per block) instead of the q5 VBR setup of the headline metric")
@@ -234,7 +250,9 @@ def main():
     params = stream_params(torch, dev, lo, hi)
     ncb = S * CHANNELS
     traffic, traffic_src = load_traffic(ncb)
-    legs = [args.only] if args.only else ["block", "pcm"]   # (the per-block leg first: the front end adds HIP streams)
+    # (the per-block leg first: the front end adds HIP streams; the solo leg last: its encoder's internal streams would
+    # change which hardware queues the streams of the timed legs land on — measured: per-block step 3.7 ms instead of 2.8)
+    legs = [args.only] if args.only else ["block", "pcm", "solo"]
 
     def barrier():
         shard.barrier()
@@ -264,8 +282,7 @@ def main():
         enc.reset()
         fe = v.FrontEnd(enc)
         gen = torch.Generator(device=dev).manual_seed(99 + lo)
-        nchunks = args.steps + args.warmup
-        chunks = [synth_pcm(torch, dev, params, gen, k * HOP, HOP) for k in range(nchunks)]   # resident in HBM
+        chunks = []
         stat = {"rounds": 0, "blocks": 0, "samples": 0, "modes": np.zeros(4, np.int64), "mean_bytes": 0.0}
         kept = []
         counting = [False]
@@ -278,14 +295,13 @@ def main():
         # behind catch up one extra block per round.  "2,1,1" (1.33 per write) keeps every stream's buffer bounded over
         # hundreds of writes (300 writes: encoded / input 0.9985, max_buffered_samples_at_end 14528 as after 48);
         # "2,1,1,1" and "1" do not (the buffers grow until a write is refused, which aborts the run).
-        # The warm-up runs three per write to clear the start of the streams, where all deliver short blocks at once.
         PATTERN = [int(x) for x in os.environ.get("VBM_BENCH_ROUNDS", "2,1,1").split(",")]
 
         def step_pcm(k):
             fe.write(chunks[k])
             if DEVICE_ROUNDS:
                 # rounds built on the device: the call only enqueues (no decision ever comes back to the host)
-                nr = 3 if k < args.warmup else PATTERN[k % len(PATTERN)]
+                nr = PATTERN[k % len(PATTERN)]
                 if counting[0]:
                     stat["rounds"] += nr
                 # lazy=2: the stream that feeds PCM never waits for packets; a consumer's stream is tied to the outputs of
@@ -318,11 +334,30 @@ def main():
             if DEVICE_ROUNDS:
                 base_stats[0] = fe.device_stats()
 
+        # Stream start-up (set-up, not warm-up): every stream begins with two or three short blocks and a transition
+        # block, all streams at the same moment, which overflows the short types' lane regions for a dozen rounds.
+        # PRIME writes with four rounds each clear that, so that warm-up and timed region see the steady state.
+        # The rest of the PRIME writes run at the steady pattern until one whole burst period (57 writes) has passed: the
+        # share of streams that are catching up after a burst has then reached its steady state (before that, fewer blocks
+        # come out than go in).
+        PRIME = int(os.environ.get("VBM_BENCH_PRIME", "64"))
+        gen_prime = torch.Generator(device=dev).manual_seed(7 + lo)
+        for k in range(PRIME):
+            fe.write(synth_pcm(torch, dev, params, gen_prime, k * HOP, HOP))
+            if DEVICE_ROUNDS:
+                kept.append(fe.encode_rounds_device(nrounds=4 if k < 10 else PATTERN[k % len(PATTERN)],
+                                                    lazy=2 if CONSUMER else LAZY_JOIN, device=dev))
+                if CONSUMER:
+                    fe.join(consumer)
+                del kept[:-6]
+            else:
+                fe.encode_rounds(min_rounds=4, max_rounds=16, headroom=HOP, device=dev)
+        fe.join()
+        torch.cuda.synchronize()
         # warmup is not counted; the timed region starts with a join so that nothing of it is left pending
         PROF_STEPS = 8
         nsteps_total = args.warmup + args.steps + PROF_STEPS
-        while len(chunks) < nsteps_total:
-            chunks.append(synth_pcm(torch, dev, params, gen, len(chunks) * HOP, HOP))
+        chunks[:] = [synth_pcm(torch, dev, params, gen, (PRIME + k) * HOP, HOP) for k in range(nsteps_total)]   # resident in HBM
         for k in range(args.warmup):
             step_pcm(k)
         count_from_now()
@@ -363,8 +398,9 @@ def main():
         else:
             nb_last = kept[-1][2]
             stat["mean_bytes"] = float(nb_last.float().mean().item()) if len(nb_last) else 0.0
+        encoded_s, input_s = stat["samples"] / RATE, S * HOP / RATE * args.steps
         results["pcm"] = dict(dt_local=dt_local, stage_ms=stage_ms, calls=calls, blocks_prof=blocks_prof, stat=stat,
-                              audio_local=stat["samples"] / RATE, prof_steps=PROF_STEPS)
+                              audio_local=min(encoded_s, input_s), encoded_s=encoded_s, input_s=input_s, prof_steps=PROF_STEPS)
         fe.close()
         del chunks, kept
 
@@ -403,11 +439,39 @@ def main():
                                 audio_local=S * HOP / RATE * args.steps, mdct_alone_ms=ms.value / 20,
                                 mean_bytes=float(last[0][1].float().mean().item()))
 
+    # ---- leg "solo": every stage of the per-block path ALONE (one HIP stream, the two mask branches one after the other:
+    #      no kernel runs beside another), HIP events between the stages on that stream.  What `roofline` is made of;
+    #      `rocprofv3 --kernel-trace --stats -- python bench.py --only solo` shows the same launches kernel by kernel
+    #      (profiles/rNN/solo_kernel_stats.csv).
+    def leg_solo():
+        os.environ["VBM_OVERLAP_BRANCHES"] = "0"
+        enc1 = v.Encoder(setup, S)
+        del os.environ["VBM_OVERLAP_BRANCHES"]
+        gen = torch.Generator(device=dev).manual_seed(1234 + lo)
+        x = synth_pcm(torch, dev, params, gen, 0, (DISTINCT_STEPS + 1) * HOP)
+        blocks = [x[:, :, k * HOP:k * HOP + N_LONG].contiguous() for k in range(DISTINCT_STEPS)]
+        del x
+        ids = np.arange(S, dtype=np.int32)
+        wflags = np.full(S, 3, dtype=np.uint8)
+        nsolo = int(os.environ.get("VBM_BENCH_SOLO_STEPS", "12"))
+        for k in range(3):
+            enc1.analysis_batch(3, ids, wflags, blocks[k % DISTINCT_STEPS])
+        torch.cuda.synchronize()
+        enc1.profile_begin(nsolo)
+        for k in range(nsolo):
+            enc1.analysis_batch(3, ids, wflags, blocks[(3 + k) % DISTINCT_STEPS])
+        torch.cuda.synchronize()
+        stage_ms, calls = enc1.profile_end()
+        results["solo"] = dict(stage_ms={k: ms_ / max(calls, 1) for k, ms_ in stage_ms.items()}, calls=calls)
+        enc1.close()
+
     for leg in legs:
-        (leg_pcm if leg == "pcm" else leg_block)()
+        {"pcm": leg_pcm, "block": leg_block, "solo": leg_solo}[leg]()
 
     # ---- reduce over ranks (gloo): max of the time, sum of the work ------------------------------------------------
-    for r in results.values():
+    for name, r in results.items():
+        if name == "solo":
+            continue
         r["dt"] = shard.max_over_ranks(r["dt_local"])
         r["value"] = shard.aggregate_throughput(r["audio_local"], r["dt_local"])
 
@@ -420,10 +484,28 @@ def main():
             dominant = max(per_step, key=per_step.get)
             return per_step, per_launch, cb, dominant
 
+        if set(results) == {"solo"}:        # (profiling runs: rocprofv3 over the solo launches only)
+            print(json.dumps({"metric": "solo stage times of the per-block path", "stage_solo_ms": results["solo"]["stage_ms"],
+                              "channel_blocks_per_launch": ncb, "launches_timed": results["solo"]["calls"]}), flush=True)
+            shard.finish()
+            return
         headline = "block" if (args.per_block or "pcm" not in results) else "pcm"
         R = results[headline]
         per_step, per_launch, cb, dominant = stage_view(R)
-        roofline = roof_of(dominant, per_launch[dominant], cb, traffic)
+        if "solo" in results:
+            # the dominant kernel = the stage that takes longest ALONE at the step's launch size (one launch per step);
+            # its duration is the HIP-event time on its own stream with nothing beside it
+            solo = results["solo"]["stage_ms"]
+            dominant = max(solo, key=solo.get)
+            roofline = roof_of(dominant, solo[dominant], ncb, traffic)
+            roofline["kernel_ms_source"] = ("HIP events around the stage's launches on their stream, leg 'solo' of this run: "
+                                            f"{results['solo']['calls']} launches of {ncb} long channel-blocks, one HIP stream, "
+                                            "nothing beside them")
+            roofline["kernels"] = STAGE_KERNELS.get(dominant, [])
+            roofline["in_situ_ms_per_step"] = per_step.get(dominant)
+            roofline["launches_per_step"] = 1
+        else:
+            roofline = roof_of(dominant, per_launch[dominant], cb, traffic)
         if traffic_src:
             roofline["traffic_source"] = traffic_src
         line = {
@@ -448,7 +530,8 @@ def main():
                 "block_switching": ("in the timed region: PCM intake, envelope search, block switching and block carve-out "
                                     "run on the device (vbm_frontend_*)" if headline == "pcm" else
                                     "not in the timed region (pre-cut long blocks)"),
-                "value_counts": "audio seconds of the blocks encoded inside the timed region, all ranks / max-over-ranks wall",
+                "value_counts": "min(audio seconds written, audio seconds of the blocks that came out) inside the timed region, "
+                                "all ranks / max-over-ranks wall",
                 "pipeline_complete": True,
                 "control_backend": shard.backend(),
                 **({"managed_bitrate": args.bitrate,
@@ -460,6 +543,10 @@ def main():
             "stage_ms_per_step": per_step,
             "stage_ms_per_launch": per_launch,
         }
+        if "solo" in results:
+            line["stage_solo_ms"] = results["solo"]["stage_ms"]
+            line["stage_solo_roofline_frac"] = {k: (STAGE_BYTES[k] * ncb / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBPS if ms_ > 0 else None)
+                                                for k, ms_ in results["solo"]["stage_ms"].items() if k in STAGE_BYTES}
         if "pcm" in results:
             st = results["pcm"]["stat"]
             line["config"].update({
@@ -471,7 +558,10 @@ def main():
                                    "transition_long": int(st["modes"][2]), "long": int(st["modes"][3])},
                 "short_block_fraction": float(st["modes"][:2].sum() / max(st["blocks"], 1)),
                 "input_audio_s_per_rank": S * HOP / RATE * args.steps,
-                "encoded_audio_s_rank0": results["pcm"]["audio_local"],
+                "encoded_audio_s_rank0": results["pcm"]["encoded_s"],
+                "encoded_over_input": results["pcm"]["encoded_s"] / results["pcm"]["input_s"],
+                "stream_start_up": "VBM_BENCH_PRIME (64) writes before the warm-up, the first ten with four rounds each: set-up (one burst "
+                                   "period of every stream has passed when the warm-up starts), not timed",
                 "mean_packet_bytes_last_call": st["mean_bytes"],
                 "rounds_built_on": "device (no host synchronisation inside the timed region)" if st.get("max_buffered_end") is not None
                                    else "host (one synchronisation per round)",
