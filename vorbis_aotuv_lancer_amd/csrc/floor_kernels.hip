@@ -159,6 +159,13 @@ __device__ __forceinline__ int post_Y(const int *A, const int *B, int pos)
     return (A[pos] + B[pos]) >> 1;
 }
 
+__device__ __forceinline__ int post_Y(const short *A, const short *B, int pos)
+{
+    if (A[pos] < 0) return B[pos];
+    if (B[pos] < 0) return A[pos];
+    return (A[pos] + B[pos]) >> 1;
+}
+
 // 64 channel-blocks x 64 bins per workgroup of 256 threads
 __global__ void k_floor_prep(vbm_batch b)
 {
@@ -461,6 +468,383 @@ __global__ void k_floor_fit(vbm_batch b, int lpw)
     b.post_valid[lane] = 1;
 }
 
+// ---------------------------------------------------------------------------------------------
+// floor1_fit, cooperative form: FG = 16 lanes per channel-block, four blocks per wavefront, one wavefront per
+// workgroup.  What the scalar source does bin by bin is spread over the lanes wherever it is integer arithmetic
+// (order free), and kept in the source's order wherever it rounds:
+//   accumulate_fit   (lib/floor1.c:427-475) the ten integer sums of every post segment: a lane takes the row eight bins
+//                    (one 16-byte load) at a time, sums what falls into one segment in registers and adds it to the
+//                    segment's entry in LDS (ds_add: integer, any order).  A post's own bin counts for the segment on
+//                    either side, as in the source's [x0, x1] ranges.
+//   fit_line         (:477-535) five double-precision accumulations over the segments of a range, each in segment order
+//                    (they round): one lane per accumulator, the two fits of a split side by side in the two halves of
+//                    the lane group; the 5 x 2 sums then go to every lane, which solves redundantly.
+//   inspect_error    (:537-586) the line's y at bin x is closed form (after k steps the walk has taken floor(k ady / adx)
+//                    long steps), mse is an integer sum and the over / under tests are integer compares: a lane enters the
+//                    line at the start of an eight-bin piece with one division and steps it from there; sums and flags
+//                    meet by shuffles.
+//   greedy split     (:646-719) serial over the posts, state (fit values, neighbours, memo) in LDS as 16-bit words:
+//                    ~1.4 KB per block with the sums — 5.6 KB per wavefront for the 29-post floor of long blocks (the
+//                    lane-per-block kernel kept 3.9 KB per LANE in scratch memory, 250 KB per wavefront).
+//   output           (:723-748) a post's value needs those of its two static neighbours, which have lower post numbers:
+//                    lanes take posts, passes repeat until nothing changes (as many as the neighbour tree is deep).
+#define FG 16
+struct fitgrp {
+    int *sums;                  // [(posts - 1) * 10]
+    short *A, *B, *lo, *hi, *memo;   // [posts] each
+    // the floor look's tables, copied once (the greedy loop reads them in a chain of dependent loads: from global
+    // memory every one of them is a round trip to L2)
+    short *sorted, *reverse, *post, *slo, *shi;   // sorted_index, reverse_index, postlist [posts]; static lo / hi neighbours [posts - 2]
+};
+#define FIT_SHORTS 10           /* 16-bit arrays of `pmax` entries per group */
+
+__device__ __forceinline__ int grp_or(int v)
+{
+    v |= __shfl_xor(v, 1); v |= __shfl_xor(v, 2); v |= __shfl_xor(v, 4); v |= __shfl_xor(v, 8);
+    return v;
+}
+__device__ __forceinline__ int grp_add(int v)
+{
+    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+    return v;
+}
+__device__ __forceinline__ int grp_max(int v)
+{
+    v = max(v, __shfl_xor(v, 1)); v = max(v, __shfl_xor(v, 2)); v = max(v, __shfl_xor(v, 4)); v = max(v, __shfl_xor(v, 8));
+    return v;
+}
+__device__ __forceinline__ int grp_min(int v)
+{
+    v = min(v, __shfl_xor(v, 1)); v = min(v, __shfl_xor(v, 2)); v = min(v, __shfl_xor(v, 4)); v = min(v, __shfl_xor(v, 8));
+    return v;
+}
+__device__ __forceinline__ void fit_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// Two fit_line calls side by side: half h = (l >> 3) of the lane group fits segments [seg0[h], seg0[h] + nfit[h]) with the
+// end values y0[h], y1[h] (in: known value or < 0; out: the fit).  ret[h] as the source's return value.  Lane r = l & 7
+// < 5 of a half owns accumulator r (xb, yb, x2b, xyb, bn); nfit[h] = 0: the half idles.  All arguments group-uniform.
+__device__ __forceinline__ void fit_line2(const fitgrp &G, const short *__restrict__ sorted_index, const int l, const int gbase,
+                                          const int seg0a, const int nfita, const int seg0b, const int nfitb, int &ya0, int &ya1,
+                                          int &yb0, int &yb1, int &reta, int &retb, const float twofitweight)
+{
+    const int h = l >> 3, r = l & 7;
+    const int seg0 = h ? seg0b : seg0a, nfit = h ? nfitb : nfita;
+    const int y0 = h ? yb0 : ya0, y1 = h ? yb1 : ya1;
+    const int x0 = sorted_index[seg0], x1 = sorted_index[seg0 + nfit];
+    double acc = 0.;
+    if (r < 5) {
+        // (the segment's addend of accumulator r, b + a * weight, was formed once after accumulate_fit: see fit_terms)
+        const double *T = reinterpret_cast<const double *>(G.sums) + r;
+        for (int i = seg0; i < seg0 + nfit; i++) acc += T[i * 5];
+        if (y0 >= 0) acc += (r == 0) ? x0 : (r == 1) ? y0 : (r == 2) ? x0 * x0 : (r == 3) ? y0 * x0 : 1;
+        if (y1 >= 0) acc += (r == 0) ? x1 : (r == 1) ? y1 : (r == 2) ? x1 * x1 : (r == 3) ? y1 * x1 : 1;
+    }
+    // the five sums of this half to all of its lanes
+    const int src = gbase + (h << 3);
+    const double xb = __shfl(acc, src), yb = __shfl(acc, src + 1), x2b = __shfl(acc, src + 2), xyb = __shfl(acc, src + 3),
+                 bn = __shfl(acc, src + 4);
+    int o0 = 0, o1 = 0, ret = 1;
+    {
+        const double denom = (bn * x2b - xb * xb);
+        if (denom > 0.) {
+            const double aa = (yb * x2b - xyb * xb) / denom;
+            const double bb = (bn * xyb - xb * yb) / denom;
+            o0 = (int)rint(aa + bb * x0);
+            o1 = (int)rint(aa + bb * x1);
+            if (o0 > 1023) o0 = 1023;
+            if (o1 > 1023) o1 = 1023;
+            if (o0 < 0) o0 = 0;
+            if (o1 < 0) o1 = 0;
+            ret = 0;
+        }
+    }
+    // results of both halves to every lane of the group (lane 0 of each half is as good as any)
+    ya0 = __shfl(o0, gbase); ya1 = __shfl(o1, gbase); reta = __shfl(ret, gbase);
+    yb0 = __shfl(o0, gbase + 8); yb1 = __shfl(o1, gbase + 8); retb = __shfl(ret, gbase + 8);
+}
+
+__global__ __launch_bounds__(64) void k_floor_fit_coop(vbm_batch b, const int pmax, const int phases)   // phases: timing experiments (31 = all)
+{
+    extern __shared__ int fitc_lds[];
+    const int lane64 = (int)threadIdx.x, g = lane64 >> 4, l = lane64 & 15, gbase = g << 4;
+    const int ncb = vbm_ncb(b);
+    const int blk = (int)blockIdx.x * 4 + g;
+    const bool live = blk < ncb;
+    const int lane = live ? blk : 0;              // (idle groups shadow block 0 and write nothing: shuffles stay whole-wave)
+    const size_t tb = (size_t)(lane >> 6) * b.slab_words + (lane & 63);
+    const vbm_setup *s = b.setup;
+    const int c = lane % b.ch;
+    const vbm_map *map = &s->map[b.W];
+    const vbm_floor *look = &s->floor[map->floorsubmap[map->chmuxlist[c]]];
+    const int n = look->n;
+    const int posts = look->posts;
+    const int nseg = posts - 1;
+    const float maxover = look->maxover, maxunder = look->maxunder, maxerr = look->maxerr;
+    const float twofitweight = look->twofitweight;
+    const int imaxover = (int)floorf(maxover), imaxunder = (int)floorf(maxunder);   // both >= 0 in every floor template
+    const uint16_t *__restrict__ row = b.qf_bm + (size_t)lane * b.n;     // 16-byte aligned: n is a multiple of 8
+
+    // per-group LDS: sums, then ten 16-bit arrays
+    const int per_grp = ((pmax - 1) * 10 + ((FIT_SHORTS * pmax + 1) >> 1) + 1) & ~1;  // ints, even: the sums become doubles
+    fitgrp G;
+    G.sums = fitc_lds + g * per_grp;
+    G.A = (short *)(G.sums + (pmax - 1) * 10);
+    G.B = G.A + pmax; G.lo = G.B + pmax; G.hi = G.lo + pmax; G.memo = G.hi + pmax;
+    G.sorted = G.memo + pmax; G.reverse = G.sorted + pmax; G.post = G.reverse + pmax; G.slo = G.post + pmax; G.shi = G.slo + pmax;
+
+    for (int k = l; k < nseg * 10; k += FG) G.sums[k] = 0;
+    for (int k = l; k < posts; k += FG) {
+        G.A[k] = -200; G.B[k] = -200; G.lo[k] = 0; G.hi[k] = 1; G.memo[k] = -1;
+        G.sorted[k] = (short)look->sorted_index[k]; G.reverse[k] = (short)look->reverse_index[k]; G.post[k] = (short)look->postlist[k];
+        if (k < posts - 2) { G.slo[k] = (short)look->loneighbor[k]; G.shi[k] = (short)look->hineighbor[k]; }
+    }
+    fit_lds_sync();
+    const short *__restrict__ sorted_index = G.sorted, *__restrict__ reverse_index = G.reverse, *__restrict__ postlist = G.post;
+
+    // ---- accumulate_fit of every minimal division (lib/floor1.c:625-628)
+    int any_a = 0;
+    {
+        const int lastp = sorted_index[posts - 1];
+        const int top = (lastp < n - 1) ? lastp : n - 1;          // last bin any segment holds
+        int sp = -1;                                              // posts strictly below the lane's current piece, less one
+        if (phases & 1)
+        for (int c8 = l; (c8 << 3) <= top; c8 += FG) {
+            const int i0 = c8 << 3;
+            const uint4 v = *reinterpret_cast<const uint4 *>(row + i0);
+            const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
+            // segment the piece starts in: sp = (posts strictly below i0) - 1, so that a post AT i0 takes the generic path
+            // (pieces come in rising order: the search goes on from where the last one ended)
+            while (sp + 1 < posts && sorted_index[sp + 1] < i0) sp++;
+            int nxt = (sp + 1 < posts) ? sorted_index[sp + 1] : 0x7fffffff;
+            int xa = 0, ya = 0, x2a = 0, xya = 0, na = 0, xb = 0, yb = 0, x2b = 0, xyb = 0, nb = 0;
+            auto flush = [&]() {
+                if ((na | nb) && sp >= 0 && sp < nseg) {
+                    int *S = G.sums + sp * 10;
+                    if (na) { atomicAdd(&S[0], xa); atomicAdd(&S[1], ya); atomicAdd(&S[2], x2a); atomicAdd(&S[3], xya); atomicAdd(&S[4], na); }
+                    if (nb) { atomicAdd(&S[5], xb); atomicAdd(&S[6], yb); atomicAdd(&S[7], x2b); atomicAdd(&S[8], xyb); atomicAdd(&S[9], nb); }
+                }
+                xa = ya = x2a = xya = na = xb = yb = x2b = xyb = nb = 0;
+            };
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int i = i0 + u;
+                if (i > top) break;
+                const int w = (int)((wd[u >> 1] >> ((u & 1) * 16)) & 0xffffu);
+                const int q = w & 0x7fff;
+                const bool cls = (w & 0x8000) != 0;
+                if (q && cls) any_a = 1;
+                auto add = [&]() {
+                    if (q) {
+                        if (cls) { xa += i; ya += q; x2a += i * i; xya += i * q; na++; }
+                        else { xb += i; yb += q; x2b += i * i; xyb += i * q; nb++; }
+                    }
+                };
+                if (i == nxt) {          // a post's bin: the end of segment sp and the start of segment sp + 1
+                    add();
+                    flush();
+                    sp++;
+                    nxt = (sp + 1 < posts) ? sorted_index[sp + 1] : 0x7fffffff;
+                }
+                add();
+            }
+            flush();
+        }
+    }
+    any_a = grp_or(any_a);
+    fit_lds_sync();
+    // fit_line adds, per segment of its range and in segment order, (double)b + (double)a * weight to each of its five
+    // sums (lib/floor1.c:490-499), weight = (float)(bn + an) * twofitweight / (float)(an + 1) + 1: the addend does not
+    // depend on the range, so every segment's five addends are formed once, in place of its ten integer sums (same 40
+    // bytes), and a fit is a chain of additions
+    {
+        double t[(VBM_VIF_POSIT + 1 + FG - 1) / FG][5];
+#pragma unroll
+        for (int u = 0; u < (VBM_VIF_POSIT + 1 + FG - 1) / FG; u++) {
+            const int sg = l + u * FG;
+            if (sg < nseg) {
+                const int *S = G.sums + sg * 10;
+                const int aan = S[4], abn = S[9];
+                const double weight = (double)((float)(abn + aan) * twofitweight / (float)(aan + 1)) + 1.;
+#pragma unroll
+                for (int r = 0; r < 5; r++) t[u][r] = S[5 + r] + S[r] * weight;
+            }
+        }
+        fit_lds_sync();
+#pragma unroll
+        for (int u = 0; u < (VBM_VIF_POSIT + 1 + FG - 1) / FG; u++) {
+            const int sg = l + u * FG;
+            if (sg < nseg) {
+                double *T = reinterpret_cast<double *>(G.sums) + sg * 5;
+#pragma unroll
+                for (int r = 0; r < 5; r++) T[r] = t[u][r];
+            }
+        }
+        fit_lds_sync();
+    }
+    if (!any_a) {      // (group-uniform) no bin above the two-fit line anywhere: no floor for this channel
+        if (live && l == 0) b.post_valid[lane] = 0;
+    }
+    // (a group without a floor walks on with its empty sums: the shuffles below want whole wavefronts; it writes nothing)
+    const bool work = live && any_a;
+
+    int y0 = -200, y1 = -200, d0 = -200, d1 = -200, r0 = 0, r1 = 0;
+    fit_line2(G, sorted_index, l, gbase, 0, posts - 1, 0, 0, y0, y1, d0, d1, r0, r1, twofitweight);
+    if (l == 0) { G.A[0] = (short)y0; G.B[0] = (short)y0; G.B[1] = (short)y1; G.A[1] = (short)y1; }
+    fit_lds_sync();
+
+    if (phases & 2)
+    for (int i = 2; i < posts; i++) {
+        const int sortpos = reverse_index[i];
+        const int ln = G.lo[sortpos], hn = G.hi[sortpos];
+        if (G.memo[ln] == hn) continue;               // (group-uniform)
+        const int lsortpos = reverse_index[ln], hsortpos = reverse_index[hn];
+        const int lx = postlist[ln], hx = postlist[hn];
+        const int ly = post_Y(G.A, G.B, ln), hy = post_Y(G.A, G.B, hn);
+        fit_lds_sync();                                // every lane has read memo / A / B
+        if (l == 0) G.memo[ln] = (short)hn;
+
+        // inspect_error (lib/floor1.c:537-586)
+        int split;
+        {
+            const int dy = hy - ly, adx = hx - lx;
+            const int base = (int)((float)dy / (float)adx);      // |dy| < 2^23: truncates like dy / adx
+            const int sy = (dy < 0 ? base - 1 : base + 1);
+            const int ady = abs(dy) - abs(base * adx);
+            int mse = 0, viol = 0;
+            if (l == 0) {
+                const int wv = row[lx];
+                const int val = wv & 0x7fff;
+                mse = (ly - val) * (ly - val);
+                if (wv & 0x8000) {
+                    if (ly + maxover < val) viol = 1;
+                    if (ly - maxunder > val) viol = 1;
+                }
+            }
+            const int xlo = lx + 1, xhi = hx - 1;
+            if (xlo <= xhi && (phases & 4)) {
+                const int blast = xhi >> 3;
+                for (int c8 = (xlo >> 3) + l; c8 <= blast; c8 += FG) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(row + (c8 << 3));
+                    const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
+                    const int xs = max(c8 << 3, xlo);
+                    // the line at bin xs: k steps after lx, q of them long ones (k ady < 2^23: float division is exact enough
+                    // to truncate to the integer quotient, see div_trunc in pack_kernels.hip)
+                    const int k = xs - lx;
+                    const int t = k * ady;
+                    const int q = (int)((float)t / (float)adx);
+                    int err = t - q * adx;
+                    int y = ly + k * base + q * (sy - base);
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int x = (c8 << 3) + u;
+                        if (x >= xs && x <= xhi) {
+                            const int wv = (int)((wd[u >> 1] >> ((u & 1) * 16)) & 0xffffu);
+                            const int val = wv & 0x7fff;
+                            const int d = y - val;
+                            mse += d * d;
+                            if ((wv & 0x8000) && val && (-d > imaxover || d > imaxunder)) viol = 1;
+                            err += ady;
+                            if (err >= adx) { err -= adx; y += sy; } else y += base;
+                        }
+                    }
+                }
+            }
+            mse = grp_add(mse);
+            viol = grp_or(viol);
+            const int cnt = 1 + ((xlo <= xhi) ? xhi - xlo + 1 : 0);
+            if (viol) split = 1;
+            else if (maxover * maxover / cnt > maxerr) split = 0;
+            else if (maxunder * maxunder / cnt > maxerr) split = 0;
+            else if (mse / cnt > maxerr) split = 1;
+            else split = 0;
+        }
+
+        if (split && (phases & 8)) {
+            int ly0 = -200, ly1 = -200, hy0 = -200, hy1 = -200, ret0 = 0, ret1 = 0;
+            fit_line2(G, sorted_index, l, gbase, lsortpos, sortpos - lsortpos, sortpos, hsortpos - sortpos, ly0, ly1, hy0, hy1,
+                      ret0, ret1, twofitweight);
+            if (ret0) { ly0 = ly; ly1 = hy0; }
+            if (ret1) { hy0 = ly1; hy1 = hy; }
+            if (ret0 && ret1) {
+                if (l == 0) { G.A[i] = -200; G.B[i] = -200; }
+            } else {
+                if (l == 0) {
+                    G.B[ln] = (short)ly0;
+                    if (ln == 0) G.A[ln] = (short)ly0;
+                    G.A[i] = (short)ly1;
+                    G.B[i] = (short)hy0;
+                    G.A[hn] = (short)hy1;
+                    if (hn == 1) G.B[hn] = (short)hy1;
+                }
+                if (ly1 >= 0 || hy0 >= 0) {
+                    // for (j = sortpos - 1; j >= 0; j--) if (hineighbor[j] == hn) hineighbor[j] = i; else break;
+                    int brk = -1;
+                    for (int j = l; j < sortpos; j += FG)
+                        if (G.hi[j] != hn) brk = j;              // (ascending: the last one found is the largest)
+                    brk = grp_max(brk);
+                    // for (j = sortpos + 1; j < posts; j++) if (loneighbor[j] == ln) loneighbor[j] = i; else break;
+                    int stop = posts;
+                    for (int j = sortpos + 1 + l; j < posts; j += FG)
+                        if (G.lo[j] != ln) { stop = j; break; }
+                    stop = grp_min(stop);
+                    fit_lds_sync();
+                    for (int j = brk + 1 + l; j < sortpos; j += FG) G.hi[j] = (short)i;
+                    for (int j = sortpos + 1 + l; j < stop; j += FG) G.lo[j] = (short)i;
+                }
+            }
+        } else {
+            if (l == 0) { G.A[i] = -200; G.B[i] = -200; }
+        }
+        fit_lds_sync();
+    }
+
+    // ---- output (lib/floor1.c:723-748): posts 0 and 1 as fitted; post i from its static neighbours' outputs.  `memo`
+    //      is free now and holds the outputs (16 bits: value | 0x8000)
+    short *out = G.memo;
+    fit_lds_sync();
+    for (int k = l; k < posts; k += FG) out[k] = (k < 2) ? (short)post_Y(G.A, G.B, k) : (short)0;
+    fit_lds_sync();
+    if (phases & 16)
+    for (int pass = 0; pass < posts; pass++) {
+        int nv[(VBM_VIF_POSIT + 2 + FG - 1) / FG];
+        int changed = 0;
+#pragma unroll
+        for (int t = 0; t < (VBM_VIF_POSIT + 2 + FG - 1) / FG; t++) {
+            const int i = 2 + l + t * FG;
+            nv[t] = 0;
+            if (i < posts) {
+                const int ln = G.slo[i - 2], hn = G.shi[i - 2];
+                // render_point (lib/floor1.c:381-395); err = ady (x - x0) < 2^23: float division truncates like the integer one
+                const int px0 = postlist[ln], px1 = postlist[hn], py0 = out[ln] & 0x7fff, py1 = out[hn] & 0x7fff;
+                const int pdy = py1 - py0, perr = abs(pdy) * (postlist[i] - px0);
+                const int poff = (int)((float)perr / (float)(px1 - px0));
+                const int predicted = (pdy < 0) ? py0 - poff : py0 + poff;
+                const int vx = post_Y(G.A, G.B, i);
+                nv[t] = (vx >= 0 && predicted != vx) ? vx : (predicted | 0x8000);
+                if (nv[t] != (int)(unsigned short)out[i]) changed = 1;
+            }
+        }
+        fit_lds_sync();
+#pragma unroll
+        for (int t = 0; t < (VBM_VIF_POSIT + 2 + FG - 1) / FG; t++) {
+            const int i = 2 + l + t * FG;
+            if (i < posts) out[i] = (short)nv[t];
+        }
+        fit_lds_sync();
+        if (!__any(changed)) break;
+    }
+    if (work) {
+        int *output = b.postT;
+        for (int k = l; k < posts; k += FG) T(output, k) = (int)(unsigned short)out[k];
+        if (l == 0) b.post_valid[lane] = 1;
+    }
+}
+
 // floor1_interpolate_fit for the blobs between the three fitted ones (lib/mapping0.c:1169-1181,
 // lib/floor1.c:752-771): 16.16 fixed-point blend; a blob has posts only if both of its ends do, and none
 // of the extra blobs has when the first fit (blob PACKETBLOBS/2) found nothing
@@ -645,28 +1029,35 @@ static inline dim3 grid_for(int lanes) { return dim3((unsigned)((lanes + 63) / 6
 
 extern "C" int vbm_launch_floor_fit(const vbm_batch *b, hipStream_t st)
 {
+    if (!b->mix_makes_qf)   // otherwise k_mix has written qf_bm already (psy_kernels.hip)
+        hipLaunchKernelGGL(k_floor_prep, dim3((unsigned)((b->ncb + 63) / 64), (unsigned)((b->n + 63) / 64)), dim3(256), 0,
+                           st, *b);
+    // Round 3: the cooperative kernel (16 lanes per block, no scratch memory) takes 0.30 ms alone on 32768 long
+    // channel-blocks where the lane-per-block kernel takes 0.60 ms — and issues three times the vector instructions
+    // for it (139 M against 47 M per launch, rocprofv3 SQ_INSTS_VALU: uniform work is replicated over a group's lanes,
+    // a fit keeps 5 of 16 lanes busy).  The step is bound by instruction issue, not by any one kernel's latency
+    // (DESIGN.md 4), so the full-size batch is faster with the lean kernel (per-block step 2.80 ms against 3.00,
+    // from PCM 4.80 against 4.94), and the cooperative one serves the small batches, whose chain of kernels is what a
+    // stream inside a run of short blocks waits for.  VBM_FLOORFIT_COOP: 0 never, 1 small batches (default), 2 always.
+    static const int coop = getenv("VBM_FLOORFIT_COOP") ? atoi(getenv("VBM_FLOORFIT_COOP")) : 1;
+    if (coop == 2 || (coop == 1 && (b->few || b->ncb <= 64 * 64))) {
+        const int pmax = b->fit_max_posts;
+        const size_t lds = (size_t)4 * (((pmax - 1) * 10 + ((10 * pmax + 1) >> 1) + 1) & ~1) * sizeof(int);
+        static const int phases = getenv("VBM_FLOORFIT_PHASES") ? atoi(getenv("VBM_FLOORFIT_PHASES")) : 31;   // timing experiments
+        hipLaunchKernelGGL(k_floor_fit_coop, dim3((unsigned)((b->ncb + 3) / 4)), dim3(64), lds, st, *b, pmax, phases);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     static const int lpw = [] {
         const char *e = getenv("VBM_FLOORFIT_LPW");   // tuning knob: lanes per wavefront of the greedy fit
         const int v = e ? atoi(e) : 64;
         return (v < 1 || v > 64) ? 64 : v;
     }();
-    if (!b->mix_makes_qf)   // otherwise k_mix has written qf_bm already (psy_kernels.hip)
-        hipLaunchKernelGGL(k_floor_prep, dim3((unsigned)((b->ncb + 63) / 64), (unsigned)((b->n + 63) / 64)), dim3(256), 0,
-                           st, *b);
-    // The segment sums in LDS for small batches: the greedy loop's fit_line calls then read them in tens of cycles
-    // (fit alone 0.59 -> 0.35 ms).  Not for a full batch: 70 KB per wavefront on every CU keeps the LDS-staged
-    // kernels of the other half of the pipeline (MDCT, couple, residue VQ) off the chip while the fit runs —
-    // measured 3.91 ms per step against 3.76 (VBM_FLOORFIT_LDS=1 forces it, VBM_FLOORFIT_PRIVATE=1 forbids it).
-    // (A variant with 8 / 16 / 32 lanes per block — bin loops split over the lanes, row, addends and fit state in
-    // LDS — was built and measured in round 2: 0.48 ms alone against 0.58, but 3.3 ms per step against 2.87 in the
-    // pipeline, where its 18 KB of LDS per wavefront keep the other half's kernels off the CUs; the per-block chain
-    // of ~27 greedy steps, each a handful of dependent reads and a double-precision solve, is what bounds either.)
     size_t lds = (size_t)(b->fit_max_posts - 1) * 10 * 64 * sizeof(int);
     static const int force = getenv("VBM_FLOORFIT_LDS") ? 1 : 0;
     static const bool allowed = hipFuncSetAttribute(reinterpret_cast<const void *>(k_floor_fit<true>),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess;
     (void)allowed;
-    if (lds <= 80 * 1024 && lpw == 64 && (force || b->few || b->ncb <= 64 * 64) && !getenv("VBM_FLOORFIT_PRIVATE"))
+    if (lds <= 80 * 1024 && lpw == 64 && (force || (coop == 0 && (b->few || b->ncb <= 64 * 64))) && !getenv("VBM_FLOORFIT_PRIVATE"))
         hipLaunchKernelGGL(k_floor_fit<true>, dim3((unsigned)((b->ncb + 63) / 64)), dim3(64), lds, st, *b, 64);
     else
         hipLaunchKernelGGL(k_floor_fit<false>, dim3((unsigned)((b->ncb + lpw - 1) / lpw)), dim3(64), 0, st, *b, lpw);
