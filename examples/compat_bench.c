@@ -1,0 +1,158 @@
+/* compat_bench — throughput of the DROP-IN path: many encoder streams driven through the reference's own entry
+ * points (include/vorbis_compat.h), host PCM in, packets back on the host; the loop per stream is the one of the
+ * reference's examples/encoder_example.c:179-236:
+ *     vorbis_analysis_buffer / vorbis_analysis_wrote
+ *     while (vorbis_analysis_blockout(&vd, &vb) == 1) {
+ *         vorbis_analysis(&vb, NULL); vorbis_bitrate_addblock(&vb);
+ *         while (vorbis_bitrate_flushpacket(&vd, &op)) consume(op);
+ *     }
+ * T host threads own M streams each; every thread writes one READ-sample chunk to each of its streams, then drains
+ * each of them.  Streams share device pools of `pool` slots (VORBIS_MI355X_POOL_STREAMS): one device round carves and
+ * encodes a block for every stream of a pool.  Plain C (gcc, pthreads), no HIP headers.
+ *
+ *   compat_bench <threads> <streams_per_thread> <pool_streams> <writes> [warmup_writes]
+ * prints one JSON line: audio seconds encoded per wall second (= streams at 1x realtime), device rounds, packet bytes.
+ */
+#define _DEFAULT_SOURCE
+#define _POSIX_C_SOURCE 200809L
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "vorbis_compat.h"
+
+#define READ 1024
+#define CH 2
+#define RATE 44100
+
+typedef struct {
+    int id, nstreams, writes, warmup;
+    vorbis_info *vi;
+    pthread_barrier_t *bar;
+    const float *pcm;          /* [period][CH] interleaved source, shared */
+    long period;
+    long long bytes, packets, samples;
+    double t0, t1;
+    int failed;
+} worker;
+
+static double now(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+static void *run(void *arg)
+{
+    worker *w = (worker *)arg;
+    const int M = w->nstreams;
+    vorbis_dsp_state *vd = (vorbis_dsp_state *)calloc(M, sizeof(*vd));
+    vorbis_block *vb = (vorbis_block *)calloc(M, sizeof(*vb));
+    ogg_packet op;
+    for (int s = 0; s < M; s++) {
+        if (vorbis_analysis_init(&vd[s], w->vi) || vorbis_block_init(&vd[s], &vb[s])) { w->failed = 1; break; }
+    }
+    pthread_barrier_wait(w->bar);
+    for (int k = 0; k < w->warmup + w->writes && !w->failed; k++) {
+        if (k == w->warmup) {
+            pthread_barrier_wait(w->bar);
+            w->t0 = now();
+            w->bytes = w->packets = w->samples = 0;
+        }
+        for (int s = 0; s < M; s++) {
+            float **buf = vorbis_analysis_buffer(&vd[s], READ);
+            /* every stream reads the shared signal at its own offset (streams differ, nothing is generated in the loop) */
+            long at = ((long)(w->id * M + s) * 7919 + (long)k * READ) % w->period;
+            for (int i = 0; i < READ; i++, at = (at + 1 == w->period) ? 0 : at + 1) {
+                buf[0][i] = w->pcm[at * CH];
+                buf[1][i] = w->pcm[at * CH + 1];
+            }
+            if (vorbis_analysis_wrote(&vd[s], READ)) { w->failed = 1; break; }
+        }
+        for (int s = 0; s < M && !w->failed; s++) {
+            while (vorbis_analysis_blockout(&vd[s], &vb[s]) == 1) {
+                if (vorbis_analysis(&vb[s], NULL) || vorbis_bitrate_addblock(&vb[s])) { w->failed = 1; break; }
+                while (vorbis_bitrate_flushpacket(&vd[s], &op)) {
+                    w->bytes += op.bytes;
+                    w->packets++;
+                    /* what the packet advances the stream by: the distance between block centres (lib/block.c:745-759) */
+                    w->samples += (vb[s].W ? 2048 : 256) / 4 + (vb[s].nW ? 2048 : 256) / 4;
+                }
+            }
+        }
+    }
+    w->t1 = now();
+    pthread_barrier_wait(w->bar);
+    for (int s = 0; s < M; s++) {
+        vorbis_block_clear(&vb[s]);
+        vorbis_dsp_clear(&vd[s]);
+    }
+    free(vd);
+    free(vb);
+    return NULL;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 5) {
+        fprintf(stderr, "usage: %s threads streams_per_thread pool_streams writes [warmup]\n", argv[0]);
+        return 2;
+    }
+    const int T = atoi(argv[1]), M = atoi(argv[2]);
+    int pool = atoi(argv[3]);
+    const int writes = atoi(argv[4]), warmup = argc > 5 ? atoi(argv[5]) : 8;
+    if (T < 1 || M < 1 || pool < 1 || writes < 1) return 2;
+    if (vorbis_mi355x_ctl(VORBIS_MI355X_POOL_STREAMS, &pool)) return 3;
+
+    /* SURVEY 8(d)-shaped signal: two sines + noise + a burst every 1.33 s, 4 s long, shared by all streams */
+    const long period = 4L * RATE;
+    float *pcm = (float *)malloc(sizeof(float) * period * CH);
+    uint32_t lcg = 12345u;
+    for (long i = 0; i < period; i++)
+        for (int c = 0; c < CH; c++) {
+            lcg = lcg * 1664525u + 1013904223u;
+            const double noise = ((lcg >> 8) / 8388608.0) - 1.0;
+            const double t = (double)i / RATE;
+            double x = 0.3 * sin(2 * M_PI * 440.0 * (c + 1) * t) + 0.2 * sin(2 * M_PI * 3000.0 * t + c) + 0.05 * noise;
+            if ((i % (RATE * 4 / 3)) < 200) x += 0.6 * noise;
+            pcm[i * CH + c] = (float)x;
+        }
+
+    vorbis_info vi;
+    vorbis_info_init(&vi);
+    if (vorbis_encode_init_vbr(&vi, CH, RATE, 0.5f)) { fprintf(stderr, "no q5 stereo mode pack\n"); return 4; }
+    pthread_barrier_t bar;
+    pthread_barrier_init(&bar, NULL, T);
+    worker *w = (worker *)calloc(T, sizeof(*w));
+    pthread_t *th = (pthread_t *)calloc(T, sizeof(*th));
+    for (int i = 0; i < T; i++) {
+        w[i].id = i; w[i].nstreams = M; w[i].writes = writes; w[i].warmup = warmup;
+        w[i].vi = &vi; w[i].bar = &bar; w[i].pcm = pcm; w[i].period = period;
+        pthread_create(&th[i], NULL, run, &w[i]);
+    }
+    double t0 = 1e300, t1 = 0;
+    long long bytes = 0, packets = 0, samples = 0;
+    int failed = 0;
+    for (int i = 0; i < T; i++) {
+        pthread_join(th[i], NULL);
+        if (w[i].t0 < t0) t0 = w[i].t0;
+        if (w[i].t1 > t1) t1 = w[i].t1;
+        bytes += w[i].bytes; packets += w[i].packets; samples += w[i].samples;
+        failed |= w[i].failed;
+    }
+    long long rounds = 0;
+    vorbis_mi355x_ctl(VORBIS_MI355X_ROUNDS, &rounds);
+    const double wall = t1 - t0, audio = (double)samples / RATE;
+    printf("{\"threads\": %d, \"streams\": %d, \"pool_streams\": %d, \"writes\": %d, \"wall_s\": %.4f, \"value\": %.1f, "
+           "\"input_audio_s\": %.1f, \"encoded_audio_s\": %.1f, \"packets\": %lld, \"packet_bytes\": %lld, "
+           "\"device_rounds_total\": %lld, \"failed\": %d}\n",
+           T, T * M, pool, writes, wall, audio / wall, (double)T * M * writes * READ / RATE, audio, packets, bytes, rounds, failed);
+    vorbis_info_clear(&vi);
+    free(pcm);
+    return failed ? 1 : 0;
+}

@@ -209,6 +209,45 @@ int vorbis_bitrate_addblock(vorbis_block *vb);
 /* 1 and *op filled (op->packet stays valid until the next blockout on vd), 0 when nothing is parked */
 int vorbis_bitrate_flushpacket(vorbis_dsp_state *vd, ogg_packet *op);
 
+/* ---- the reference's INTERNAL plugin seam for this path -------------------------------------------------------
+ * lib/backends.h:121-128 (vorbis_func_mapping), instance mapping0_exportbundle lib/mapping0.c:1500-1506, table
+ * _mapping_P lib/registry.c:42-44; vorbis_analysis reaches mapping0_forward through it: lib/analysis.c:45-46
+ *     ret = _mapping_P[ci->map_type[ci->mode_param[vb->mode]->mapping]]->forward(vb)
+ * A libvorbis that keeps its OWN vorbis_analysis_blockout (host PCM ring, envelope detector) and its own
+ * vorbis_bitrate_* plugs the device in here and nowhere else: it replaces its table entry by
+ * &mapping0_exportbundle_mi355x (or calls vbm_mapping0_forward where it called mapping0_forward).
+ *   in   vb->vd        a vorbis_dsp_state made by THIS library's vorbis_analysis_init (its slot carries the stream's
+ *                      encoder state — aoTuV's mblock / tblock / lW_block_mode ..., lib/codec_internal.h:85-92 — on the device)
+ *        vb->pcm       host pointers [channels][vb->pcmend]: the block as lib/block.c:653-698 carves it (un-windowed)
+ *        vb->lW, vb->W, vb->nW, vb->pcmend = blocksizes[W]
+ *        vb->internal  the caller's vorbis_block_internal, whose leading members are (lib/codec_internal.h:42-49)
+ *                      { float **pcmdelay; float ampmax; int blocktype; oggpack_buffer *packetblob[15]; } = the struct
+ *                      below; blocktype as lib/block.c:620-638 sets it (BLOCKTYPE_IMPULSE 0 / PADDING 1 for short
+ *                      blocks, TRANSITION 0 / LONG 1 for long ones)
+ *   out  the block's packet (VBR: packetblob[PACKETBLOBS/2]; managed setups: the packet the stream's reservoirs chose) in
+ *        vb->opb (buffer / ptr / endbyte, valid until the stream's next call) and, when vbi->packetblob[7] is not NULL,
+ *        copied into that oggpack_buffer (its buffer grown with realloc, as libogg's own writer grows it), so that the
+ *        caller's vorbis_bitrate_addblock / _flushpacket find it where mapping0_forward leaves it (lib/mapping0.c:1204-1313).
+ *   returns 0, OV_EINVAL for a malformed block, OV_EFAULT for a device failure.
+ * The blocks of one stream must come in stream order (the reference's contract too); blocks of different streams may
+ * come from different threads.  One call = a batch of one through vbm_analysis_batch; the batched forms
+ * (vbm_analysis_batch / _round, include/vorbis_mi355x.h) are what a caller with many streams uses. */
+typedef struct vorbis_block_internal {
+  float **pcmdelay;
+  float ampmax;
+  int blocktype;
+  oggpack_buffer *packetblob[15];
+} vorbis_block_internal;
+typedef struct vorbis_func_mapping {
+  void (*pack)(vorbis_info *, void *, oggpack_buffer *);
+  void *(*unpack)(vorbis_info *, oggpack_buffer *);
+  void (*free_info)(void *);
+  int (*forward)(struct vorbis_block *vb);
+  int (*inverse)(struct vorbis_block *vb, void *);
+} vorbis_func_mapping;
+int vbm_mapping0_forward(vorbis_block *vb);
+extern const vorbis_func_mapping mapping0_exportbundle_mi355x;   /* forward = vbm_mapping0_forward; the header / decode members are NULL */
+
 /* ---- include/vorbis/vorbisenc.h:59, :157 ---------------------------------------------------------- */
 int vorbis_encode_init_vbr(vorbis_info *vi, long channels, long rate, float base_quality);
 int vorbis_encode_init(vorbis_info *vi, long channels, long rate, long max_bitrate, long nominal_bitrate,

@@ -134,3 +134,15 @@ class Stream:
         self.dll.vorbis_block_clear(self.vb)
         self.dll.vorbis_dsp_clear(self.vd)
         self.dll.vorbis_info_clear(self.vi)
+
+
+class VorbisBlockInternal(C.Structure):
+    """leading members of the reference's vorbis_block_internal (lib/codec_internal.h:42-49)"""
+    _fields_ = [("pcmdelay", C.c_void_p), ("ampmax", C.c_float), ("blocktype", C.c_int),
+                ("packetblob", C.POINTER(OggpackBuffer) * 15)]
+
+
+class VorbisFuncMapping(C.Structure):
+    """vorbis_func_mapping (lib/backends.h:121-128)"""
+    _fields_ = [("pack", C.c_void_p), ("unpack", C.c_void_p), ("free_info", C.c_void_p),
+                ("forward", C.CFUNCTYPE(C.c_int, C.POINTER(VorbisBlock))), ("inverse", C.c_void_p)]

@@ -27,9 +27,20 @@ def test_library_exports_the_references_entry_points():
                  "vorbis_analysis_buffer", "vorbis_analysis_wrote", "vorbis_analysis_blockout", "vorbis_block_init",
                  "vorbis_block_clear", "vorbis_dsp_clear", "vorbis_encode_init_vbr", "vorbis_analysis_headerout"):
         assert need in syms
-    dll = ctypes.CDLL(v.LIB_PATH)
+    dll = ctypes.CDLL(v.COMPAT_LIB_PATH)
     missing = [s for s in syms if not hasattr(dll, s)]
     assert not missing, missing
+    # ... and ONLY the shim does: the main library exports vbm_* alone, so that it can live beside the real libvorbis / libogg
+    core = ctypes.CDLL(v.LIB_PATH)
+    leaked = [s for s in syms if s.startswith(("vorbis_", "ogg_")) and _exported(v.LIB_PATH, s)]
+    assert not leaked, leaked
+    assert hasattr(core, "vbm_analysis_batch")
+
+
+def _exported(path, name):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout
+    return any(line.split()[-1] == name for line in out.splitlines() if line.strip())
 
 
 def test_library_exports_every_declared_symbol():

@@ -60,7 +60,7 @@ def test_public_struct_layouts(tmp_path):
 @pytest.fixture(scope="module")
 def dll():
     import vorbis_aotuv_lancer_amd as v
-    return compat.bind(C.CDLL(v.LIB_PATH))
+    return compat.bind(C.CDLL(v.COMPAT_LIB_PATH))
 
 
 def test_setup_selection_and_errors(dll):

@@ -71,7 +71,7 @@ def oracle_streams(oracle, ch, rate, q, sigs, bitrate=None, chunk=1024):
 @pytest.fixture()
 def dll():
     import vorbis_aotuv_lancer_amd as v
-    d = compat.bind(C.CDLL(v.LIB_PATH))
+    d = compat.bind(C.CDLL(v.COMPAT_LIB_PATH))
     one = C.c_int(1)
     d.vorbis_mi355x_ctl(2, C.byref(one))     # VORBIS_MI355X_CARVE_AHEAD back to its default
     return d

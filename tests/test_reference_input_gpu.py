@@ -85,7 +85,7 @@ def test_windowed_sine_then_eos(oracle, cuda, ch, rate, q):
     fe.close()
 
     # the reference's own call sequence (test/write_read.c:85-115)
-    dll = compat.bind(C.CDLL(v.LIB_PATH))
+    dll = compat.bind(C.CDLL(v.COMPAT_LIB_PATH))
     st = compat.Stream(dll, ch, rate, q)
     assert st.write(pcm) == 0
     assert st.finish() == 0

@@ -9,6 +9,9 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvorbis_mi355x.so")
+# the reference's own entry points (include/vorbis_compat.h: vorbis_analysis, vorbis_bitrate_*, ogg_stream_* ...) are a
+# separate shim library over this one: nothing here loads it, a process gets those global names only by asking for them
+COMPAT_LIB_PATH = os.path.join(_HERE, "libvorbis_mi355x_compat.so")
 
 
 class VbmError(RuntimeError):

@@ -26,6 +26,8 @@
 #include "vorbis_mi355x.h"
 #include "vbm_internal.h"
 
+#define VBM_PACKETBLOBS_HALF 7       /* PACKETBLOBS / 2, lib/backends.h */
+
 namespace {
 
 struct cpool;
@@ -58,6 +60,7 @@ struct cstream {                     // vd->backend_state
     cblock parked;                   // bm->vb of the reference: added, not yet flushed
     bool parked_valid = false;
     cblock out;                      // storage of the packet vorbis_bitrate_flushpacket returned last
+    std::vector<uint8_t> seam_pkt;   // storage of the packet vbm_mapping0_forward produced last
     std::vector<uint8_t> hdr[3];     // header packets handed out by vorbis_analysis_headerout
 };
 
@@ -739,6 +742,64 @@ extern "C" int vorbis_bitrate_flushpacket(vorbis_dsp_state *vd, ogg_packet *op)
     s->parked_valid = false;
     return 1;
 }
+
+// ---- the reference's internal plugin seam (lib/backends.h:121-128, lib/mapping0.c:1500-1506, lib/registry.c:42-44) --
+// mapping0_forward(vorbis_block *vb) for a block the CALLER carved (vb->pcm on the host): a batch of one through
+// vbm_analysis_batch on the stream's device slot.  The caller keeps its own blockout and bitrate management.
+extern "C" int vbm_mapping0_forward(vorbis_block *vb)
+{
+    if (!vb || !vb->vd || !vb->pcm || !vb->internal) return OV_EINVAL;
+    cstream *s = stream_of(vb->vd);
+    if (!s) return OV_EINVAL;
+    cpool *p = s->pool;
+    cclass *c = p->cls;
+    const vorbis_block_internal *vbi = (const vorbis_block_internal *)vb->internal;
+    const int W = vb->W ? 1 : 0, N = c->bs[W], ch = c->ch;
+    if (vb->pcmend != N || (vbi->blocktype & ~1) || (c->bs[0] == c->bs[1] && W)) return OV_EINVAL;
+    for (int k = 0; k < ch; k++)
+        if (!vb->pcm[k]) return OV_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    const size_t per = (size_t)ch * N;
+    if (pool_stage(p, per)) return OV_EFAULT;
+    (void)hipStreamSynchronize(p->q);                    // the staging buffer is free
+    for (int k = 0; k < ch; k++) memcpy(p->h_pcm + (size_t)k * N, vb->pcm[k], (size_t)N * sizeof(float));
+    const int block_mode = vbi->blocktype | (W << 1);    // psy_look = b->psy + blocktype + (W ? 2 : 0), lib/mapping0.c:764
+    const int id = s->slot;
+    const uint8_t wf = (uint8_t)((vb->lW ? 1 : 0) | (vb->nW ? 2 : 0));
+    if (hipMemcpyAsync(p->d_pcm, p->h_pcm, per * sizeof(float), hipMemcpyHostToDevice, p->q) != hipSuccess) return OV_EFAULT;
+    if (vbm_analysis_batch(p->enc, block_mode, 1, &id, &wf, p->d_pcm, p->d_pkt, p->d_len, p->q)) return OV_EFAULT;
+    if (hipMemcpyAsync(p->h_len, p->d_len, sizeof(int), hipMemcpyDeviceToHost, p->q) != hipSuccess ||
+        hipStreamSynchronize(p->q) != hipSuccess) return OV_EFAULT;
+    const int bytes = p->h_len[0];
+    if (bytes < 0 || bytes > p->maxb) return OV_EFAULT;  // a packet outgrew max_packet_bytes: never silently truncated
+    s->seam_pkt.resize((size_t)bytes);
+    if (bytes && hipMemcpy(s->seam_pkt.data(), p->d_pkt, (size_t)bytes, hipMemcpyDeviceToHost) != hipSuccess) return OV_EFAULT;
+    vb->mode = W;
+    vb->glue_bits = vb->time_bits = vb->floor_bits = vb->res_bits = 0;
+    vb->opb.buffer = vb->opb.ptr = s->seam_pkt.data();
+    vb->opb.endbyte = bytes;
+    vb->opb.endbit = 0;
+    vb->opb.storage = bytes;
+    oggpack_buffer *o = vbi->packetblob[VBM_PACKETBLOBS_HALF];
+    if (o) {                                              // where mapping0_forward leaves the packet (lib/mapping0.c:1204-1313)
+        if (!o->buffer || o->storage < bytes + 1) {
+            unsigned char *nb = (unsigned char *)realloc(o->buffer, (size_t)bytes + 256);
+            if (!nb) return OV_EFAULT;
+            o->buffer = nb;
+            o->storage = bytes + 256;
+        }
+        if (bytes) memcpy(o->buffer, s->seam_pkt.data(), (size_t)bytes);
+        o->buffer[bytes] = 0;
+        o->ptr = o->buffer + bytes;
+        o->endbyte = bytes;
+        o->endbit = 0;
+    }
+    return 0;
+}
+
+#if !defined(__HIP_DEVICE_COMPILE__)    // (this file goes through hipcc: a host function's address means nothing to the device pass)
+extern "C" const vorbis_func_mapping mapping0_exportbundle_mi355x = {nullptr, nullptr, nullptr, &vbm_mapping0_forward, nullptr};
+#endif
 
 // ---- page framing under libogg's names (include/vorbis_compat.h) -------------------------------------------
 extern "C" int ogg_stream_init(ogg_stream_state *os, int serialno)
