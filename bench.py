@@ -159,6 +159,38 @@ def cpu_baseline(seconds_of_audio=600):
                       f"each, block switching + envelope search included), oracle/ scalar C, {wall:.1f} s wall"}
 
 
+def compat_path():
+    """The DROP-IN path (include/vorbis_compat.h): examples/compat_bench drives 16384 streams through the reference's own
+    entry points — vorbis_analysis_buffer / _wrote / _blockout, vorbis_analysis, vorbis_bitrate_addblock / _flushpacket, the loop
+    of the reference's examples/encoder_example.c:179-236 — from 4 host threads that own one device pool of 4096 streams
+    each; host PCM in, packets back on the host (H2D / D2H inside).  Two delivery modes: the reference's (every block as
+    soon as the stream has it) and VORBIS_MI355X_DEFER_BLOCKS (same packets, a lagging stream's extra blocks come later)."""
+    import subprocess
+    exe = os.path.join(ROOT, "examples", "compat_bench")
+    try:
+        if not os.path.exists(exe):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "compat_bench"], stdout=subprocess.DEVNULL,
+                                  stderr=subprocess.DEVNULL)
+        out = {}
+        threads, per, writes = 4, STREAMS_PER_GPU // 4, 32
+        for name, defer in (("reference_delivery", "0"), ("deferred_delivery", "1")):
+            env = dict(os.environ, VORBIS_MI355X_DEFER_BLOCKS=defer)
+            r = subprocess.run([exe, str(threads), str(per), str(per), str(writes), "8"], capture_output=True, text=True,
+                               timeout=120, env=env)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode or not line:
+                return {"error": f"compat_bench failed (rc {r.returncode}): {r.stderr[-200:]}"}
+            d = json.loads(line[-1])
+            out[name] = {"value": d["value"], "wall_s": d["wall_s"], "device_rounds": d["device_rounds_total"],
+                         "encoded_over_input": d["encoded_audio_s"] / d["input_audio_s"]}
+        best = max(out, key=lambda k: out[k]["value"])
+        return {"value": out[best]["value"], "mode": best, "unit": "x realtime (streams at 1x) through vorbis_analysis_* / "
+                "vorbis_bitrate_*, host PCM in, host packets out", "streams": threads * per, "threads": threads,
+                "pool_streams": per, "writes_timed": writes, **out}
+    except (OSError, subprocess.SubprocessError, ValueError) as e:
+        return {"error": str(e)}
+
+
 def roof_of(stage, ms_per_launch, channel_blocks, traffic):
     alg = STAGE_BYTES[stage] * channel_blocks
     ach = alg / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
@@ -587,6 +619,11 @@ def main():
             line["mdct_roofline"] = r_mdct
         if not args.no_cpu_baseline and world == 1:   # host baseline: rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline()
+        if world == 1 and not args.only and not args.bitrate and not os.environ.get("VBM_BENCH_NO_COMPAT"):
+            # (outside the headline: what a user of the reference's own API gets; the bench's device objects are gone by now)
+            enc.close()
+            torch.cuda.synchronize()
+            line["compat_path"] = compat_path()
         print(json.dumps(line), flush=True)
     shard.finish()
 

@@ -31,6 +31,8 @@
 
 typedef struct {
     int id, nstreams, writes, warmup;
+    vorbis_dsp_state *vd;      /* this thread's streams: made by main() one thread after the other, so that they fill whole pools */
+    vorbis_block *vb;
     vorbis_info *vi;
     pthread_barrier_t *bar;
     const float *pcm;          /* [period][CH] interleaved source, shared */
@@ -51,12 +53,9 @@ static void *run(void *arg)
 {
     worker *w = (worker *)arg;
     const int M = w->nstreams;
-    vorbis_dsp_state *vd = (vorbis_dsp_state *)calloc(M, sizeof(*vd));
-    vorbis_block *vb = (vorbis_block *)calloc(M, sizeof(*vb));
+    vorbis_dsp_state *vd = w->vd;
+    vorbis_block *vb = w->vb;
     ogg_packet op;
-    for (int s = 0; s < M; s++) {
-        if (vorbis_analysis_init(&vd[s], w->vi) || vorbis_block_init(&vd[s], &vb[s])) { w->failed = 1; break; }
-    }
     pthread_barrier_wait(w->bar);
     for (int k = 0; k < w->warmup + w->writes && !w->failed; k++) {
         if (k == w->warmup) {
@@ -88,12 +87,6 @@ static void *run(void *arg)
     }
     w->t1 = now();
     pthread_barrier_wait(w->bar);
-    for (int s = 0; s < M; s++) {
-        vorbis_block_clear(&vb[s]);
-        vorbis_dsp_clear(&vd[s]);
-    }
-    free(vd);
-    free(vb);
     return NULL;
 }
 
@@ -130,11 +123,17 @@ int main(int argc, char **argv)
     pthread_barrier_init(&bar, NULL, T);
     worker *w = (worker *)calloc(T, sizeof(*w));
     pthread_t *th = (pthread_t *)calloc(T, sizeof(*th));
+    /* slots are handed out pool after pool in the order streams are made: thread i's M streams first, then thread i + 1's —
+     * with pool_streams == M (or a divisor) a pool belongs to one thread, whose rounds then never wait for another thread's */
     for (int i = 0; i < T; i++) {
         w[i].id = i; w[i].nstreams = M; w[i].writes = writes; w[i].warmup = warmup;
         w[i].vi = &vi; w[i].bar = &bar; w[i].pcm = pcm; w[i].period = period;
-        pthread_create(&th[i], NULL, run, &w[i]);
+        w[i].vd = (vorbis_dsp_state *)calloc(M, sizeof(vorbis_dsp_state));
+        w[i].vb = (vorbis_block *)calloc(M, sizeof(vorbis_block));
+        for (int s = 0; s < M; s++)
+            if (vorbis_analysis_init(&w[i].vd[s], &vi) || vorbis_block_init(&w[i].vd[s], &w[i].vb[s])) { fprintf(stderr, "vorbis_analysis_init failed\n"); return 5; }
     }
+    for (int i = 0; i < T; i++) pthread_create(&th[i], NULL, run, &w[i]);
     double t0 = 1e300, t1 = 0;
     long long bytes = 0, packets = 0, samples = 0;
     int failed = 0;
@@ -152,6 +151,11 @@ int main(int argc, char **argv)
            "\"input_audio_s\": %.1f, \"encoded_audio_s\": %.1f, \"packets\": %lld, \"packet_bytes\": %lld, "
            "\"device_rounds_total\": %lld, \"failed\": %d}\n",
            T, T * M, pool, writes, wall, audio / wall, (double)T * M * writes * READ / RATE, audio, packets, bytes, rounds, failed);
+    for (int i = 0; i < T; i++)
+        for (int s = 0; s < M; s++) {
+            vorbis_block_clear(&w[i].vb[s]);
+            vorbis_dsp_clear(&w[i].vd[s]);
+        }
     vorbis_info_clear(&vi);
     free(pcm);
     return failed ? 1 : 0;

@@ -74,6 +74,8 @@ def dll():
     d = compat.bind(C.CDLL(v.COMPAT_LIB_PATH))
     one = C.c_int(1)
     d.vorbis_mi355x_ctl(2, C.byref(one))     # VORBIS_MI355X_CARVE_AHEAD back to its default
+    zero = C.c_int(0)
+    d.vorbis_mi355x_ctl(5, C.byref(zero))    # VORBIS_MI355X_DEFER_BLOCKS off
     return d
 
 
@@ -83,12 +85,17 @@ def rounds(dll):
     return n.value
 
 
-def test_many_streams_through_the_reference_api(oracle, cuda, dll):
+@pytest.mark.parametrize("defer", [0, 1])
+def test_many_streams_through_the_reference_api(oracle, cuda, dll, defer):
     """24 stereo q5 streams, each with its own vorbis_info / vorbis_dsp_state / vorbis_block, fed and drained in
-    the application's order; streams of different length (end of stream at different times)."""
+    the application's order; streams of different length (end of stream at different times).  defer = 1:
+    VORBIS_MI355X_DEFER_BLOCKS, the throughput mode (a block may be handed out later than the reference would; the
+    packets and their order per stream are the same)."""
     ch, rate, q, NS = 2, 44100, 0.5, 24
     pool = C.c_int(32)
     dll.vorbis_mi355x_ctl(1, C.byref(pool))
+    dflag = C.c_int(defer)
+    dll.vorbis_mi355x_ctl(5, C.byref(dflag))
     lens = [(18 + 3 * (s % 5)) * 1024 + (0 if s % 2 else 333) for s in range(NS)]
     sigs = [synth_signal(ch, rate, lens[s], seed=900 + s, level=1.0 if s % 3 else 0.05) for s in range(NS)]
     want = oracle_streams(oracle, ch, rate, q, sigs)

@@ -54,6 +54,8 @@ struct cstream {                     // vd->backend_state
     bool eof_sent = false;           // ... on the device
     bool over = false;               // the e_o_s block has been carved
     bool dirty = false;              // something arrived since a round last had no block for this stream
+    int given_since_write = 0;       // blocks handed out since the stream's last vorbis_analysis_wrote (VORBIS_MI355X_DEFER_BLOCKS)
+    long writes_seen = 0;
     std::deque<cblock> ready;        // carved, not yet handed out by vorbis_analysis_blockout
     cblock cur;                      // the block vorbis_analysis_blockout handed out last
     bool cur_valid = false, cur_analysed = false;
@@ -65,6 +67,7 @@ struct cstream {                     // vd->backend_state
 };
 
 struct cpool {
+    std::mutex mu;                   // everything below and the slots' streams: calls on streams of different pools run side by side
     cclass *cls = nullptr;
     vbm_encoder *enc = nullptr;
     vbm_frontend *fe = nullptr;
@@ -84,7 +87,7 @@ struct cpool {
 };
 
 struct cclass {                      // vi->codec_setup; one per mode pack, shared by every vorbis_info that names it
-    std::mutex mu;
+    std::mutex mu;                   // the pool list and the hand-out of slots
     std::string leaf;
     int refs = 0;
     long bitrate[3] = {0, 0, 0};     // nominal, lower, upper
@@ -98,6 +101,7 @@ std::mutex g_mu;                     // the class registry and the knobs below
 std::map<std::string, cclass *> g_classes;
 int g_pool_streams = 0;
 int g_carve_ahead = 1;
+int g_defer_blocks = -1;             // -1: environment VORBIS_MI355X_DEFER_BLOCKS, default 0
 std::string g_data_dir;
 long long g_rounds = 0;
 
@@ -393,6 +397,7 @@ extern "C" int vorbis_mi355x_ctl(int request, void *arg)
         g_pool_streams = *(int *)arg;
         return 0;
     case VORBIS_MI355X_CARVE_AHEAD: g_carve_ahead = *(int *)arg != 0; return 0;
+    case VORBIS_MI355X_DEFER_BLOCKS: g_defer_blocks = *(int *)arg != 0; return 0;
     case VORBIS_MI355X_DATA_DIR: g_data_dir = (const char *)arg; return 0;
     case VORBIS_MI355X_ROUNDS: *(long long *)arg = g_rounds; return 0;
     }
@@ -534,6 +539,7 @@ extern "C" int vorbis_analysis_init(vorbis_dsp_state *v, vorbis_info *vi)
         c->pools.push_back(p);
         slot = 0;
     }
+    std::lock_guard<std::mutex> lkp(p->mu);
     if (p->used_before[slot]) {
         if (vbm_frontend_restart_streams(p->fe, &slot, 1, p->q)) return 1;
         p->buffered[slot] = c->bs[1] / 2;
@@ -560,6 +566,7 @@ extern "C" void vorbis_dsp_clear(vorbis_dsp_state *v)
     if (s) {
         cclass *c = s->pool->cls;
         std::lock_guard<std::mutex> lk(c->mu);
+        std::lock_guard<std::mutex> lkp(s->pool->mu);
         s->pool->slots[s->slot] = nullptr;
         delete s;
     }
@@ -628,7 +635,7 @@ extern "C" int vorbis_analysis_wrote(vorbis_dsp_state *v, int vals)
     if (!s) return OV_EINVAL;
     cpool *p = s->pool;
     cclass *c = p->cls;
-    std::lock_guard<std::mutex> lk(c->mu);
+    std::lock_guard<std::mutex> lk(p->mu);
     if (s->eof_asked || s->eof_sent) return OV_EINVAL;
     if (vals <= 0) {
         s->eof_asked = true;
@@ -646,6 +653,8 @@ extern "C" int vorbis_analysis_wrote(vorbis_dsp_state *v, int vals)
     for (int k = 0; k < c->ch; k++) memcpy(w.data.data() + (size_t)k * vals, s->ptrs[k], vals * sizeof(float));
     s->writes.push_back(std::move(w));
     s->dirty = true;
+    s->given_since_write = 0;
+    s->writes_seen++;
     v->pcm_current += vals;
     v->preextrapolate = 1;
     return 0;
@@ -658,10 +667,22 @@ extern "C" int vorbis_analysis_blockout(vorbis_dsp_state *v, vorbis_block *vb)
     if (!s || !vb) return 0;
     cpool *p = s->pool;
     cclass *c = p->cls;
-    std::lock_guard<std::mutex> lk(c->mu);
+    std::lock_guard<std::mutex> lk(p->mu);
+    int carve, defer;
+    {
+        std::lock_guard<std::mutex> lk2(g_mu);
+        carve = g_carve_ahead;
+        if (g_defer_blocks < 0) g_defer_blocks = getenv("VORBIS_MI355X_DEFER_BLOCKS") ? atoi(getenv("VORBIS_MI355X_DEFER_BLOCKS")) != 0 : 0;
+        defer = g_defer_blocks;
+    }
+    // VORBIS_MI355X_DEFER_BLOCKS: a stream that has had its block for this write (two every third write) is told "more
+    // data needed" although the device might carve another one — a stream inside a run of short blocks would otherwise
+    // make the whole pool run up to eight more rounds per write, each for a handful of blocks.  The blocks come later
+    // (latest when the stream's buffer is half full, or at end of stream): same packets, later delivery.
+    if (defer && !s->eof_sent && !s->eof_asked && s->ready.empty() &&
+        s->given_since_write >= 1 + (s->writes_seen % 3 == 0) && p->buffered[s->slot] <= p->capacity / 2)
+        return 0;
     if (s->ready.empty() && s->dirty && !(s->over)) {
-        int carve;
-        { std::lock_guard<std::mutex> lk2(g_mu); carve = g_carve_ahead; }
         if (pool_upload(p, carve ? nullptr : s)) return 0;
         if (s->ready.empty()) {
             bool got = false;
@@ -672,6 +693,7 @@ extern "C" int vorbis_analysis_blockout(vorbis_dsp_state *v, vorbis_block *vb)
     if (s->ready.empty()) return 0;
     s->cur = std::move(s->ready.front());
     s->ready.pop_front();
+    s->given_since_write++;
     s->cur_valid = true;
     s->cur_analysed = false;
     const vbm_packet_info &pi = s->cur.info;
@@ -725,7 +747,7 @@ extern "C" int vorbis_bitrate_addblock(vorbis_block *vb)
     cstream *s = stream_of(vb->vd);
     if (!s || !s->cur_valid || vb->internal != &s->cur || !s->cur_analysed) return OV_EINVAL;
     if (s->parked_valid && !s->pool->cls->managed) return -1;          // one submitted without being claimed (:92)
-    s->parked = s->cur;
+    s->parked = s->cur;               // (vb keeps describing s->cur: a copy, as the reference's bm->vb keeps the block)
     s->parked_valid = true;
     return 0;
 }
@@ -758,7 +780,7 @@ extern "C" int vbm_mapping0_forward(vorbis_block *vb)
     if (vb->pcmend != N || (vbi->blocktype & ~1) || (c->bs[0] == c->bs[1] && W)) return OV_EINVAL;
     for (int k = 0; k < ch; k++)
         if (!vb->pcm[k]) return OV_EINVAL;
-    std::lock_guard<std::mutex> lk(c->mu);
+    std::lock_guard<std::mutex> lk(p->mu);
     const size_t per = (size_t)ch * N;
     if (pool_stage(p, per)) return OV_EFAULT;
     (void)hipStreamSynchronize(p->q);                    // the staging buffer is free
