@@ -91,6 +91,13 @@ struct vbm_batch {
     uint8_t *packetT_blob;          // [PACKETBLOBS] packet tiles, each laid out like packetT
     int *packet_bytes_blob;         // [PACKETBLOBS][Ls]
     int *choice;                    // [Ls] bm->choice of the block
+    // Fused packet assembly (k_pack_fused, pack_kernels.hip): one wavefront per stream-block, codewords in LDS.  Setups with
+    // one residue submap whose channels form ONE coded vector (stereo coupled res2, mono) on the lane-per-bin couple kernel.
+    int pack_fused;                 // the batch takes that path (host decision, configure())
+    int *res_bm;                    // [nsb][n * ch] quantised residue as the residue coder reads it: bin-interleaved channels
+                                    //   (work[x] = in[x % ch][x / ch], lib/res0.c:781-787), written by k_couple_fast
+                                    //   instead of the tiled iworkT rows when pack_fused
+                                    // packetT then holds ROWS: [sb][max_packet_bytes], only the packet's own bytes written
     int pack_submaps;               // residue submaps of this block type and their partition counts (host copy)
     int pack_partvals[16];
     int pack_spp[16];               // samples per partition (residue grouping) of each submap

@@ -307,6 +307,7 @@ extern "C" int vbm_encoder_create(vbm_encoder **out, vbm_setup_handle *setup, in
     A(b.mdct_bm, float, L * nmax);
     A(b.logfft_bm, float, L * nmax);
     A(b.qf_bm, uint16_t, L * nmax);
+    A(b.res_bm, int, L * nmax);
     A(b.local_ampmax, float, L);
     A(b.wflags_cb, uint8_t, L);
     // tiled slabs (batch.h): every per-bin array of a 64-lane tile sits in one contiguous slab
@@ -534,6 +535,21 @@ static void configure(vbm_encoder *e, vbm_batch &b, int block_mode, int nsb, con
             if (m.coupling_steps == 0) b.couple_fast = 1;
             else if (m.coupling_steps == 1 && e->ch == 2 && b.couple_parallel) b.couple_fast = 2;
         }
+        // fused packet assembly: one submap, its channels one coded vector, couple kernel = the lane-per-bin one (it writes
+        // the residue in the coder's own order).  Opt-in (VBM_PACK_FUSED=1): it moves 0.2 GB per step instead of 0.9, issues
+        // the same vector instructions as the three-kernel path (136 M against 150 M per step: the cascaded VQ is ~100
+        // instructions per vector either way) and holds 21 KB of LDS per stream-block while it does — a wavefront of the
+        // lane-per-block kernels holds 8 KB for 64 of them — which keeps the other half of the pipeline off the CUs:
+        // pack alone 0.80 ms against 0.64, from PCM 4.81 ms per step against 4.67.
+        {
+            static const int want = getenv("VBM_PACK_FUSED") ? atoi(getenv("VBM_PACK_FUSED")) : 0;
+            const vbm_residue &r0 = s->residue[m.residuesubmap[0]];
+            const int nbch = e->ch;
+            b.pack_fused = want && !s->managed && m.submaps == 1 && b.couple_fast &&
+                           ((r0.type == 2 && (r0.grouping % nbch) == 0 && (r0.begin % nbch) == 0) || e->ch == 1) &&
+                           r0.end <= b.n * nbch && r0.phrase_dim >= 1 && r0.phrase_dim <= 8 &&
+                           (r0.end - r0.begin) / r0.grouping <= 64;     // a lane per partition
+        }
         b.pack_submaps = m.submaps;
         for (int i = 0; i < m.submaps && i < 16; i++) {
             const vbm_residue &r = s->residue[m.residuesubmap[i]];
@@ -554,7 +570,7 @@ static vbm_batch slice_of(const vbm_batch &f, int sb0, int nsb, uint8_t *d_packe
     v.nsb = nsb;
     v.ncb = nsb * f.ch;
     v.stream_id += sb0; v.wflags += sb0;
-    v.pcm += cb0 * f.N; v.mdct_bm += cb0 * f.n; v.logfft_bm += cb0 * f.n; v.qf_bm += cb0 * f.n;
+    v.pcm += cb0 * f.N; v.mdct_bm += cb0 * f.n; v.logfft_bm += cb0 * f.n; v.qf_bm += cb0 * f.n; v.res_bm += cb0 * f.n;
     v.local_ampmax += cb0; v.wflags_cb += cb0; v.poste += cb0; v.post_valid += cb0; v.nonzero += cb0;
     v.post_valid_blob += cb0;
     v.global_ampmax += sb0; v.packet_bytes += sb0; v.packet_bits += sb0;
@@ -748,6 +764,10 @@ extern "C" int vbm_analysis_batch2(vbm_encoder *e, int block_mode, int nsb, cons
             STAGE(10, q, RUN(vbm_launch_pack(&v, q)));
         }
         STAGE(11, q, {
+            if (v.pack_fused) {
+                RUN(vbm_launch_packets_out(&v, d_packets ? d_packets + (size_t)sb0 * e->max_packet_bytes : nullptr,
+                                           d_packet_bytes ? d_packet_bytes + sb0 : nullptr, q));
+            } else {
             if (d_packets && !s->managed)   // word-major tiles -> [nsb][max_packet_bytes] bytes (little-endian words)
                 RUN(vbm_launch_untranspose_i32((const int *)v.packetT,
                                                (int *)(d_packets + (size_t)sb0 * e->max_packet_bytes),
@@ -756,6 +776,7 @@ extern "C" int vbm_analysis_batch2(vbm_encoder *e, int block_mode, int nsb, cons
             if (d_packet_bytes) {
                 if ((err = hipMemcpyAsync(d_packet_bytes + sb0, v.packet_bytes, v.nsb * sizeof(int), hipMemcpyDeviceToDevice, q)) != hipSuccess)
                     return vbm_set_hip_error(err, "hipMemcpyAsync(packet_bytes)");
+            }
             }
         });
         return 0;
@@ -897,10 +918,12 @@ static int enqueue_job(vbm_encoder *e, const type_job &j)
     if (j.grouped) return VBM_OK;     // the group's caller copies the outputs and records the events
     vbm_debug_delay_point(VBM_DP_JOB_OUT, q);
     { TIMED(11, q);
+      if (v.pack_fused) RUN(vbm_launch_packets_out(&v, j.d_packets, j.d_packet_bytes, q));
+      else {
       if (j.d_packets && !s->managed)
           RUN(vbm_launch_untranspose_counted((const int *)v.packetT, (int *)j.d_packets, e->max_packet_bytes / 4,
                                              (size_t)(e->max_packet_bytes / 4) * 64, v.nsb, v.d_nsb, q));
-      if (j.d_packet_bytes) RUN(vbm_launch_copy_counted(j.d_packet_bytes, v.packet_bytes, v.nsb, v.d_nsb, q)); }
+      if (j.d_packet_bytes) RUN(vbm_launch_copy_counted(j.d_packet_bytes, v.packet_bytes, v.nsb, v.d_nsb, q)); } }
 #undef TIMED
     if ((err = hipEventRecord(e->ev_done[w][m], q)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
     return VBM_OK;
@@ -915,6 +938,7 @@ static int copy_outputs(vbm_encoder *e, const type_job &j, hipStream_t q)
     vbm_batch v = slice_of(full, j.lane0, j.bound);
     v.d_nsb = j.d_nsb;
     if (e->hs->managed) return VBM_OK;   // (managed_back delivers the chosen packets itself)
+    if (v.pack_fused) { RUN(vbm_launch_packets_out(&v, j.d_packets, j.d_packet_bytes, q)); return VBM_OK; }
     if (j.d_packets)
         RUN(vbm_launch_untranspose_counted((const int *)v.packetT, (int *)j.d_packets, e->max_packet_bytes / 4,
                                            (size_t)(e->max_packet_bytes / 4) * 64, v.nsb, v.d_nsb, q));
@@ -1582,6 +1606,12 @@ extern "C" int vbm_encoder_fetch(vbm_encoder *e, const char *name, void *d_out, 
         {"floor_out", b.floor_outT, VBM_VIF_POSIT + 2, 'i', b.ncb},
         {"residue", b.iworkT, b.n, 'i', b.ncb},
     };
+    if (b.pack_fused && !strcmp(name, "residue")) {   // the couple kernel wrote the coder's interleaved order (res_bm), not the tiles
+        if (rows_out) *rows_out = b.n;
+        if (kind) *kind = 'i';
+        if (!d_out) return VBM_OK;
+        return vbm_launch_res_bm_rows(&b, (int *)d_out, st) ? VBM_EHIP : VBM_OK;
+    }
     for (const Ent &t : table) {
         if (strcmp(t.name, name)) continue;
         if (rows_out) *rows_out = t.rows < 0 ? b.n : t.rows;

@@ -573,9 +573,10 @@ __global__ __launch_bounds__(64) void k_floor_fit_coop(vbm_batch b, const int pm
     extern __shared__ int fitc_lds[];
     const int lane64 = (int)threadIdx.x, g = lane64 >> 4, l = lane64 & 15, gbase = g << 4;
     const int ncb = vbm_ncb(b);
+    if ((int)blockIdx.x * 4 >= ncb) return;       // (the launch covers the batch's bound; the count lives on the device)
     const int blk = (int)blockIdx.x * 4 + g;
     const bool live = blk < ncb;
-    const int lane = live ? blk : 0;              // (idle groups shadow block 0 and write nothing: shuffles stay whole-wave)
+    const int lane = live ? blk : 0;              // (idle groups of the last wavefront shadow block 0 and write nothing: shuffles stay whole-wave)
     const size_t tb = (size_t)(lane >> 6) * b.slab_words + (lane & 63);
     const vbm_setup *s = b.setup;
     const int c = lane % b.ch;

@@ -20,6 +20,11 @@ int vbm_launch_floor_fit(const vbm_batch *b, hipStream_t st);
 int vbm_launch_floor_encode(const vbm_batch *b, hipStream_t st);
 int vbm_launch_couple_quantize(const vbm_batch *b, hipStream_t st);
 int vbm_launch_pack(const vbm_batch *b, hipStream_t st);          // = pack_head, then pack_residue
+// packets of the batch to the caller's buffers: dst [nsb][max_packet_bytes] (bytes past a packet's length zero), lengths to dst_bytes;
+// either may be NULL; d_nsb as in vbm_batch (device-resident count or NULL).  Handles both packet layouts (tiles / fused rows).
+int vbm_launch_packets_out(const vbm_batch *b, uint8_t *dst, int *dst_bytes, hipStream_t st);
+// the quantised residue of a pack_fused batch as block-major rows [channel-block][n] (parity tests)
+int vbm_launch_res_bm_rows(const vbm_batch *b, int *dst, hipStream_t st);
 int vbm_launch_pack_head(const vbm_batch *b, hipStream_t st);     // header + floor bits: may run beside couple/quantise
 int vbm_launch_pack_residue(const vbm_batch *b, hipStream_t st);  // after both: nonzero propagation, residue class + VQ + bits
 // tiled [col>>6][rows][64] (tile stride `slab` elements) -> block-major dst[col][rows]

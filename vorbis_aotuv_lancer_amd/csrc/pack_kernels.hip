@@ -28,6 +28,7 @@
 // through unused entries.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 #include "batch.h"
 #include "kernels.h"
 
@@ -191,6 +192,83 @@ __device__ __forceinline__ int besterror(const book_regs *book, int *a)
     if (index > -1)
         for (i = 0; i < dim; i++) a[i] -= p[i];
     return index;
+}
+
+// local_book_besterror split in two for the fused kernel.  vq_lattice: the lattice step (lib/res0.c:316-341) — quantise every
+// component, index of the lattice point, the point itself in p[]; returns true when that entry has no codeword, i.e. the
+// exhaustive search of :343-370 has to find the nearest entry that has one.  That search is rare per vector and long (it
+// visits every used entry): run by the lane that needs it, it makes the whole wavefront wait for `used` steps whenever ANY
+// of its 64 vectors needs it.  vq_search_wave instead serves one such vector with all 64 lanes: lane l scores the used
+// entries l, l + 64, ... and a wave reduction picks the minimum, the lowest entry on ties (the source keeps the first).
+__device__ __forceinline__ bool vq_lattice(const book_regs *book, const int *a, int &index, int *p)
+{
+    const int dim = book->dim;
+    const int minval = book->minval, del = book->delta, qv = book->quantvals;
+    const int ze = (qv >> 1);
+    index = 0;
+    int i, o;
+    if (del != 1) {
+        for (i = 0, o = dim; i < dim; i++) {
+            int v = div_trunc(a[--o] - minval + (del >> 1), del);
+            int m = (v < ze ? ((ze - v) << 1) - 1 : ((v - ze) << 1));
+            index = index * qv + (m < 0 ? 0 : (m >= qv ? qv - 1 : m));
+            p[o] = v * del + minval;
+        }
+    } else {
+        for (i = 0, o = dim; i < dim; i++) {
+            int v = a[--o] - minval;
+            int m = (v < ze ? ((ze - v) << 1) - 1 : ((v - ze) << 1));
+            index = index * qv + (m < 0 ? 0 : (m >= qv ? qv - 1 : m));
+            p[o] = v * del + minval;
+        }
+    }
+    return book->lengthlist[index] <= 0;
+}
+
+// the vector av[] (the same in every lane) against all used entries; returns the position in the used list (every lane)
+__device__ __forceinline__ int vq_search_wave(const book_regs *book, const int *av, const int lane)
+{
+    const int dim = book->dim, used = book->used;
+    bool small = book->used_pack != nullptr;
+    for (int j = 0; j < dim; j++) small = small && (av[j] >= -32768 && av[j] <= 32767);
+    long long best = 0x7fffffffffffffffLL;       // (score << 32) | position: one compare orders by score, then by position
+    if (small) {
+        typedef short short2v __attribute__((ext_vector_type(2)));
+        uint32_t pa[4] = {0u, 0u, 0u, 0u};
+        for (int j = 0; j < dim; j++) pa[j >> 1] |= ((uint32_t)av[j] & 0xffffu) << ((j & 1) * 16);
+        const uint4 *pk = reinterpret_cast<const uint4 *>(book->used_pack);
+        const int *__restrict__ nrm = book->used_norm;
+        const int words = (dim + 1) >> 1;
+        for (int i = lane; i < used; i += 64) {
+            const uint4 v = pk[i];
+            int dot = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, v.x), __builtin_bit_cast(short2v, pa[0]), 0, false);
+            if (words > 1) dot = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, v.y), __builtin_bit_cast(short2v, pa[1]), dot, false);
+            if (words > 2) {
+                dot = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, v.z), __builtin_bit_cast(short2v, pa[2]), dot, false);
+                dot = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, v.w), __builtin_bit_cast(short2v, pa[3]), dot, false);
+            }
+            const long long key = ((long long)(nrm[i] - 2 * dot) << 32) | (unsigned)i;
+            if (key < best) best = key;
+        }
+    } else {
+        const int *pt0 = book->used_point;
+        for (int i = lane; i < used; i += 64) {
+            const int *pt = pt0 + (size_t)i * dim;
+            int dist = 0;
+            for (int j = 0; j < dim; j++) {
+                const int val = pt[j] - av[j];
+                dist += val * val;
+            }
+            const long long key = ((long long)dist << 32) | (unsigned)i;
+            if (key < best) best = key;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const long long o = __shfl_xor(best, off);
+        if (o < best) best = o;
+    }
+    return (int)(best & 0xffffffffLL);
 }
 
 // which channels of submap `sm` take part, and the residue's vector shape
@@ -801,6 +879,396 @@ __global__ void k_res_emit(vbm_batch b, int sm, int nchunks)
         }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Fused packet assembly: ONE wavefront per stream-block does what k_pack_head + k_nonzero_propagate + k_res_vq +
+// k_res_offsets + k_res_emit (+ the zero fill before and the layout change after) do for setups whose residue is ONE
+// coded vector (stereo coupled res2, mono res1).  Nothing but the packet leaves the wavefront:
+//   work    the vector as the residue coder reads it (k_couple_fast leaves it bin-interleaved in res_bm) in LDS, one pad
+//           word per partition so that lane i walking partition i meets its own banks
+//   floors  a lane per (channel, floor partition): codeword lengths first, a wave scan for the bit positions, then the
+//           codewords are OR-ed into the packet words in LDS (floor1_encode's emission order, lib/floor1.c:856-942)
+//   class   res*_class per partition, a lane each (lib/res0.c:406-526)
+//   stages  _01forward (lib/res0.c:528-640): per stage every lane runs the cascade step of ITS partition
+//           (local_book_besterror :316-378 on the remainder in LDS) and leaves (codeword, length) per vector in LDS; the
+//           bit position of every partition's run is the scan of the run lengths in emission order (phrase codewords
+//           in front of their group at stage 0); then each lane ORs its run in.  Stage by stage, because a stage's
+//           positions start where the stage before ended.
+//   out     the packet's own words to row sb of the packet buffer ([sb][max_packet_bytes]; nothing is cleared, nothing
+//           is transposed: vbm_launch_packets_out copies length bytes and zero-fills the caller's row behind them)
+#define PF_WAVE 64
+__device__ __forceinline__ void lds_or_bits(uint32_t *words, const int maxwords, const int pos, uint32_t value, const int bits)
+{
+    if (bits <= 0) return;
+    if (bits < 32) value &= (1u << bits) - 1u;
+    const uint64_t v = (uint64_t)value << (pos & 31);
+    const int wi = pos >> 5;
+    if (wi < maxwords) atomicOr(&words[wi], (uint32_t)v);
+    if ((v >> 32) && wi + 1 < maxwords) atomicOr(&words[wi + 1], (uint32_t)(v >> 32));
+}
+
+// inclusive prefix sum over the wavefront
+__device__ __forceinline__ int wave_incl_scan(int v, const int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(v, d);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// One floor item of channel c: it = 0 the channel's lead-in (the "floor present" bit and the two end posts), it >= 1 floor
+// partition it - 1 (class codeword + its posts' codewords, lib/floor1.c:873-942).  pos < 0: count bits only; else emit at pos.
+__device__ int pf_floor_item(const vbm_batch &b, const vbm_setup *s, const vbm_floor *look, const size_t col, const int it,
+                             uint32_t *pkt, const int maxwords, int pos)
+{
+    const size_t SW = b.slab_words;
+#define OUTV(x) b.floor_outT[(size_t)(col >> 6) * SW + (size_t)(x) * 64 + (col & 63)]
+    int bits = 0;
+    auto put = [&](uint32_t code, int len) {
+        if (len <= 0) return;
+        if (pos >= 0) { lds_or_bits(pkt, maxwords, pos, code, len); pos += len; }
+        bits += len;
+    };
+    if (it == 0) {
+        const int qb = ilog(look->quant_q - 1);
+        put(1u, 1);
+        put((uint32_t)OUTV(0), qb);
+        put((uint32_t)OUTV(1), qb);
+        return bits;
+    }
+    const int i = it - 1;
+    int j = 2;
+    for (int t = 0; t < i; t++) j += look->class_dim[look->partitionclass[t]];
+    const int cls = look->partitionclass[i];
+    const int cdim = look->class_dim[cls];
+    const int csubbits = look->class_subs[cls];
+    const int csub = 1 << csubbits;
+    int cval = 0, cshift = 0;
+    // which subbook every post takes (:880-893), the class codeword, then the posts' own codewords
+    for (int k = 0; k < cdim; k++) {
+        const int ov = OUTV(j + k);
+        int bk = 0;
+        if (csubbits) {
+            for (int l = 0; l < csub; l++) {
+                const int booknum = look->class_subbook[cls][l];
+                const int maxval = booknum < 0 ? 1 : s->book[booknum].entries;
+                if (ov < maxval) { bk = l; break; }
+            }
+            cval |= bk << cshift;
+            cshift += csubbits;
+        }
+    }
+    if (csubbits) {
+        const vbm_book *cb = &s->book[look->class_book[cls]];
+        if (cval >= 0 && cval < cb->entries) put(cb->codelist[cval], cb->lengthlist[cval]);
+    }
+    cshift = 0;
+    for (int k = 0; k < cdim; k++) {
+        const int ov = OUTV(j + k);
+        const int bk = csubbits ? (cval >> cshift) & (csub - 1) : 0;
+        cshift += csubbits;
+        const int book = look->class_subbook[cls][bk];
+        if (book >= 0) {
+            const vbm_book *sb_ = &s->book[book];
+            if (ov >= 0 && ov < sb_->entries) put(sb_->codelist[ov], sb_->lengthlist[ov]);
+        }
+    }
+#undef OUTV
+    return bits;
+}
+
+__global__ __launch_bounds__(PF_WAVE) void k_pack_fused(vbm_batch b)
+{
+    extern __shared__ int pf_lds[];
+    const int sb = (int)blockIdx.x, lane = (int)threadIdx.x;
+    if (sb >= vbm_nsb(b)) return;
+    const vbm_setup *s = b.setup;
+    const vbm_map *info = &s->map[b.W];
+    const int ch = b.ch;
+    const size_t col0 = (size_t)sb * ch;
+    const vbm_residue *r = &s->residue[info->residuesubmap[0]];
+    const int spp = r->grouping, pv = (r->end - r->begin) / spp, rbegin = r->begin;
+    const int spad = spp + 1;
+    const int maxwords = b.max_packet_bytes / 4;
+    // LDS: work [pv * spad] | code [pv * spad] | pkt [maxwords] | len bytes [pv * spad] | class bytes [pv] | order bytes [pv]
+    int *work = pf_lds;
+    uint32_t *code = (uint32_t *)(work + pv * spad);
+    uint32_t *pkt = code + pv * spad;
+    uint8_t *len = (uint8_t *)(pkt + maxwords);
+    uint8_t *pcls = len + pv * spad;
+
+    for (int k = lane; k < maxwords; k += PF_WAVE) pkt[k] = 0u;
+    // ---- the vector into LDS (k_couple_fast left it in the coder's order: work[x], x = bin * ch + channel)
+    {
+        const int *src = b.res_bm + (size_t)sb * b.n * ch + rbegin;
+        // (x / spp without a division per element: spp is a power of two in every shipped setup)
+        const int sh = (spp & (spp - 1)) == 0 ? __ffs(spp) - 1 : -1;
+        if (sh >= 0)
+            for (int x = lane; x < pv * spp; x += PF_WAVE) work[x + (x >> sh)] = src[x];
+        else
+            for (int x = lane; x < pv * spp; x += PF_WAVE) work[x + x / spp] = src[x];
+    }
+    // ---- nonzero[] after coupling (lib/psy.c:5133-5140)
+    int nzbits = 0;
+    for (int c = 0; c < ch; c++) nzbits |= (b.nonzero[col0 + c] ? 1 : 0) << c;
+    for (int i = 0; i < info->coupling_steps; i++) {
+        const int m = info->coupling_mag[i], a = info->coupling_ang[i];
+        if (((nzbits >> m) | (nzbits >> a)) & 1) nzbits |= (1 << m) | (1 << a);
+    }
+    if (lane < ch) b.nonzero[col0 + lane] = (nzbits >> lane) & 1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+    // ---- packet type, mode number, window flags (lib/mapping0.c:1211-1218)
+    int pos = 1 + s->modebits + (b.W ? 2 : 0);
+    if (lane == 0) {
+        uint32_t h = 0;                              // bit 0: packet type 0
+        h |= (uint32_t)b.W << 1;
+        if (b.W) h |= ((uint32_t)(b.wflags[sb] & 1) << (1 + s->modebits)) | ((uint32_t)((b.wflags[sb] >> 1) & 1) << (2 + s->modebits));
+        lds_or_bits(pkt, maxwords, 0, h, pos);
+    }
+    // ---- floors, channel by channel (lib/floor1.c:856-942): a lane per item, lengths -> scan -> emit
+    for (int c = 0; c < ch; c++) {
+        const size_t col = col0 + c;
+        const vbm_floor *look = &s->floor[info->floorsubmap[info->chmuxlist[c]]];
+        if (!b.post_valid[col]) { pos += 1; continue; }            // a zero bit: nothing to OR
+        const int items = 1 + look->partitions;                     // <= 32
+        int bits = 0;
+        if (lane < items) bits = pf_floor_item(b, s, look, col, lane, pkt, maxwords, -1);
+        const int incl = wave_incl_scan(bits, lane);
+        if (lane < items) (void)pf_floor_item(b, s, look, col, lane, pkt, maxwords, pos + incl - bits);
+        pos += __shfl(incl, 63);
+    }
+
+    // ---- residue: the channels of the (single) submap as one vector
+    const bool used = (r->type == 2) ? (nzbits != 0) : (nzbits & 1);
+    if (used) {
+        // classification (res*_class): lane i = partition i
+        const int nclass = r->partitions;
+        const int *__restrict__ classmetric1 = r->classmetric1, *__restrict__ classmetric2 = r->classmetric2;
+        for (int i = lane; i < pv; i += PF_WAVE) {
+            const int *w = work + i * spad;
+            int k;
+            if (r->type == 2) {
+                // _2class (lib/res0.c:473-526): magnitude = the first channel's samples, angle = all the others
+                int magmax = 0, angmax = 0;
+                int cc = (rbegin + i * spp) % ch;                  // channel of the partition's first sample
+                for (int e = 0; e < spp; e++) {
+                    const int a = abs(w[e]);
+                    if (cc == 0) { if (a > magmax) magmax = a; }
+                    else if (a > angmax) angmax = a;
+                    if (++cc == ch) cc = 0;
+                }
+                for (k = 0; k < nclass - 1; k++)
+                    if (magmax <= classmetric1[k] && angmax <= classmetric2[k]) break;
+            } else {
+                // _01class (lib/res0.c:406-468)
+                const float scale = (float)(100. / spp);
+                int mx = 0, ent = 0;
+                for (int e = 0; e < spp; e++) {
+                    const int a = abs(w[e]);
+                    if (a > mx) mx = a;
+                    ent += a;
+                }
+                ent = (int)((float)ent * scale);
+                for (k = 0; k < nclass - 1; k++)
+                    if (mx <= classmetric1[k] && (classmetric2[k] < 0 || ent < classmetric2[k])) break;
+            }
+            pcls[i] = (uint8_t)k;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+        // partitions in class order (stable): order[base[k] + rank] = the rank-th partition of class k.  pv <= 64 here
+        // (configure()): lane i = partition i.
+        uint8_t *order = pcls + pv;
+        const int mycls = lane < pv ? pcls[lane] : -1;
+        {
+            int basek = 0;
+            for (int k = 0; k < nclass; k++) {
+                const unsigned long long m = __ballot(mycls == k);
+                if (mycls == k) order[basek + __popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+                basek += __popcll(m);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+        const vbm_book *phrasebook = &s->book[r->groupbook];
+        const int pd = r->phrase_dim;
+        for (int st = 0; st < r->stages; st++) {
+            // ---- the cascade step of every vector of the stage, class by class: all lanes of a pass share the book (its
+            //      fields are wave-uniform: scalar loads), a lane takes one vector (partition order[..], vector t)
+            {
+                int basek = 0;
+                for (int k = 0; k < nclass; k++) {
+                    const int cnt = __popcll(__ballot(mycls == k));
+                    const int bi = (r->secondstages[k] & (1 << st)) ? r->partbook[k][st] : -1;
+                    if (bi >= 0 && cnt > 0) {
+                        const book_regs bk = load_book(&s->book[bi]);
+                        const int dim = bk.dim, nvec = spp / dim, items = cnt * nvec;
+                        const int vsh = (nvec & (nvec - 1)) == 0 ? __ffs(nvec) - 1 : -1;     // (wave-uniform)
+                        for (int id0 = 0; id0 < items; id0 += PF_WAVE) {        // (wave-uniform trip count)
+                            const int id = id0 + lane;
+                            const bool act = id < items;
+                            const int rnk = vsh >= 0 ? (id >> vsh) : id / nvec, t = id - rnk * nvec;
+                            const int i = act ? order[basek + rnk] : 0;
+                            const int wo = i * spad + t * dim;                   // where the vector lives in `work`
+                            int a[VBM_MAX_BOOK_DIM], pnt[VBM_MAX_BOOK_DIM];
+                            int index = -1;
+                            bool need = false;
+                            if (act) {
+                                for (int d = 0; d < dim; d++) a[d] = work[wo + d];
+                                need = vq_lattice(&bk, a, index, pnt);
+                            }
+                            // vectors whose lattice point has no codeword: the nearest entry that has one, found by the whole wavefront
+                            for (unsigned long long m = __ballot(need); m; m &= m - 1) {
+                                const int src = __ffsll((long long)m) - 1;
+                                const int so = __shfl(wo, src);
+                                int av[VBM_MAX_BOOK_DIM];
+                                for (int d = 0; d < dim; d++) av[d] = work[so + d];
+                                const int bj = vq_search_wave(&bk, av, lane);
+                                if (lane == src && bk.used > 0) {
+                                    const int *pt = bk.used_point + (size_t)bj * dim;
+                                    for (int d = 0; d < dim; d++) pnt[d] = pt[d];
+                                    index = bk.used_index[bj];
+                                }
+                            }
+                            if (act) {
+                                if (index > -1)
+                                    for (int d = 0; d < dim; d++) work[wo + d] = a[d] - pnt[d];
+                                uint32_t c_ = 0;
+                                int l_ = 0;
+                                if (index >= 0 && index < bk.entries) { l_ = bk.lengthlist[index]; c_ = bk.codelist[index]; }
+                                code[i * spad + t] = c_;
+                                len[i * spad + t] = (uint8_t)l_;
+                            }
+                        }
+                    }
+                    basek += cnt;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            // ---- lane i = partition i: its run's length, the positions in emission order ([phrase of the group] run(i)
+            //      run(i + 1) ... per group, lib/res0.c:574-636), then the run is OR-ed into the packet
+            {
+                const int i = lane;
+                const bool mine = i < pv;
+                int runbits = 0, phlen = 0, nvec = 0;
+                uint32_t phcode = 0;
+                if (mine) {
+                    if (st == 0 && (i % pd) == 0) {
+                        long val = mycls;
+                        for (int k = 1; k < pd; k++) {
+                            val *= nclass;
+                            if (i + k < pv) val += pcls[i + k];
+                        }
+                        if (val < phrasebook->entries) { phlen = phrasebook->lengthlist[val]; phcode = phrasebook->codelist[val]; }
+                    }
+                    const int bi = (r->secondstages[mycls] & (1 << st)) ? r->partbook[mycls][st] : -1;
+                    if (bi >= 0) {
+                        nvec = spp / s->book[bi].dim;
+                        const uint8_t *cl = len + i * spad;
+                        for (int t = 0; t < nvec; t++) runbits += cl[t];
+                    }
+                }
+                const int mybits = runbits + phlen;
+                const int incl = wave_incl_scan(mybits, lane);
+                int at = pos + incl - mybits;
+                if (mine) {
+                    if (phlen > 0) { lds_or_bits(pkt, maxwords, at, phcode, phlen); at += phlen; }
+                    const uint32_t *cw = code + i * spad;
+                    const uint8_t *cl = len + i * spad;
+                    // (a run goes in word by word through a 64-bit accumulator: one LDS atomic per 32 bits, not per codeword)
+                    int wi = at >> 5, nb_ = at & 31;
+                    uint64_t acc = 0;
+                    for (int t = 0; t < nvec; t++) {
+                        const int l_ = cl[t];
+                        if (l_) {
+                            acc |= (uint64_t)cw[t] << nb_;
+                            nb_ += l_;
+                            if (nb_ >= 32) {
+                                if (wi < maxwords) atomicOr(&pkt[wi], (uint32_t)acc);
+                                acc >>= 32;
+                                nb_ -= 32;
+                                wi++;
+                            }
+                        }
+                    }
+                    if (nb_ > 0 && wi < maxwords) atomicOr(&pkt[wi], (uint32_t)acc);
+                }
+                pos += __shfl(incl, 63);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // ---- the packet's own words to its row
+    const bool over = pos > maxwords * 32;
+    const int bytes = over ? -1 : (pos + 7) / 8;
+    if (lane == 0) { b.packet_bytes[sb] = bytes; b.packet_bits[sb] = pos; }
+    if (!over) {
+        uint32_t *row = (uint32_t *)(b.packetT + (size_t)sb * b.max_packet_bytes);
+        const int nw = (bytes + 3) >> 2;
+        for (int k = lane; k < nw; k += PF_WAVE) row[k] = pkt[k];
+    }
+}
+
+// rows of a fused batch to the caller: length bytes copied, the rest of the caller's row zero (16 bytes per lane and step)
+__global__ __launch_bounds__(256) void k_rows_out(vbm_batch b, uint8_t *__restrict__ dst, int *__restrict__ dst_bytes)
+{
+    const int sb = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
+    if (sb >= vbm_nsb(b)) return;
+    const int bytes = b.packet_bytes[sb];
+    if (dst_bytes && lane == 0) dst_bytes[sb] = bytes;
+    if (!dst) return;
+    const int maxb = b.max_packet_bytes;
+    const uint4 *src = (const uint4 *)(b.packetT + (size_t)sb * maxb);
+    uint4 *out = (uint4 *)(dst + (size_t)sb * maxb);
+    const int live = bytes > 0 ? bytes : 0;
+    for (int k = lane; k < maxb / 16; k += 64) {
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        const int at = k * 16;
+        if (at < live) {
+            v = src[k];
+            const int keep = live - at;                // bytes of this piece inside the packet
+            if (keep < 16) {
+                uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                for (int q = 0; q < 4; q++) {
+                    const int kq = keep - 4 * q;
+                    if (kq <= 0) w[q] = 0u;
+                    else if (kq < 4) w[q] &= (1u << (8 * kq)) - 1u;
+                }
+                v = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+        }
+        out[k] = v;
+    }
+}
+
+// res_bm [sb][bin * ch + c] -> rows [sb * ch + c][bin]
+__global__ void k_res_bm_rows(vbm_batch b, int *__restrict__ dst)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)vbm_nsb(b) * b.n * b.ch;
+    if (idx >= total) return;
+    const size_t per = (size_t)b.n * b.ch;
+    const size_t sb = idx / per, x = idx - sb * per;
+    const int bin = (int)(x / b.ch), c = (int)(x - (size_t)bin * b.ch);
+    dst[(sb * b.ch + c) * b.n + bin] = b.res_bm[idx];
+}
+
 }  // namespace
 
 extern "C" int vbm_launch_block_state(const vbm_batch *b, hipStream_t st)
@@ -864,6 +1332,48 @@ extern "C" int vbm_launch_pack_residue(const vbm_batch *b, hipStream_t st)
 
 extern "C" int vbm_launch_pack(const vbm_batch *b, hipStream_t st)
 {
+    if (b->pack_fused) {
+        const vbm_setup *hs = nullptr; (void)hs;
+        // LDS: work + code (4 B each per padded slot), the packet words, a length byte per slot, a class byte per partition
+        const int spp = b->pack_spp[0], pv = b->pack_partvals[0];
+        const size_t slots = (size_t)pv * (spp + 1);
+        size_t lds = slots * 8 + (size_t)b->max_packet_bytes + slots + 2 * (size_t)pv;
+        lds = (lds + 15) & ~(size_t)15;
+        static std::mutex mu;
+        static size_t allowed = 48 * 1024;
+        {
+            std::lock_guard<std::mutex> guard(mu);
+            if (lds > allowed) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_pack_fused), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds) != hipSuccess) return -2;
+                allowed = lds;
+            }
+        }
+        hipLaunchKernelGGL(k_pack_fused, dim3((unsigned)b->nsb), dim3(PF_WAVE), lds, st, *b);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     int rc = vbm_launch_pack_head(b, st);
     return rc ? rc : vbm_launch_pack_residue(b, st);
+}
+
+extern "C" int vbm_launch_packets_out(const vbm_batch *b, uint8_t *dst, int *dst_bytes, hipStream_t st)
+{
+    if (!dst && !dst_bytes) return 0;
+    if (b->pack_fused) {
+        hipLaunchKernelGGL(k_rows_out, dim3((unsigned)((b->nsb + 3) / 4)), dim3(256), 0, st, *b, dst, dst_bytes);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
+    int rc = 0;
+    if (dst) rc = vbm_launch_untranspose_counted((const int *)b->packetT, (int *)dst, b->max_packet_bytes / 4,
+                                                 (size_t)(b->max_packet_bytes / 4) * 64, b->nsb, b->d_nsb, st);
+    if (!rc && dst_bytes) rc = vbm_launch_copy_counted(dst_bytes, b->packet_bytes, b->nsb, b->d_nsb, st);
+    return rc;
+}
+
+extern "C" int vbm_launch_res_bm_rows(const vbm_batch *b, int *dst, hipStream_t st)
+{
+    const size_t total = (size_t)b->nsb * b->n * b->ch;
+    if (!total) return 0;
+    hipLaunchKernelGGL(k_res_bm_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, *b, dst);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
 }

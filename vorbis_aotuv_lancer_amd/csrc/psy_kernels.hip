@@ -465,6 +465,7 @@ __global__ void k_mix(vbm_batch b, int nchunks)
     __shared__ uint16_t qtile[QF ? 64 : 1][66];
     __shared__ uint8_t colact[64];
     const int lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if ((int)(blockIdx.x * blockDim.x) >= vbm_ncb(b)) return;        // (launch bound > device-resident count)
     // managed bitrate: the hi / lo rate passes run only for channels whose first fit exists (lib/mapping0.c:1097)
     const bool active = lane < vbm_ncb(b) && !(MANAGED && SEL != 1 && !b.post_valid_blob[(size_t)(VBM_PACKETBLOBS / 2) * b.L + lane]);
     __shared__ int s_bfn[M0 ? 256 : 1];

@@ -694,6 +694,7 @@ template <int MODE>
 __global__ __launch_bounds__(FP * FPC) void k_couple_fast(vbm_batch b)
 {
     __shared__ fast_lds L;
+    if ((int)(blockIdx.x * FPC) >= ((MODE == 1) ? vbm_nsb(b) : vbm_ncb(b))) return;   // (launch bound > device-resident count)
     const vbm_setup *s = b.setup;
     const vbm_psy *p = &s->psy[b.block_mode];
     const vbm_map *vi = &s->map[b.W];
@@ -851,7 +852,22 @@ __global__ __launch_bounds__(FP * FPC) void k_couple_fast(vbm_batch b)
         }
     }
 
-    // ---- store: back through LDS so that rows go out coalesced ---------------------------------
+    // ---- store.  Fused packet assembly (k_pack_fused): the residue goes out in the residue coder's own order — bin-interleaved
+    //      channels, res_bm[column][bin * NCH + channel] (lib/res0.c:781-787) — straight from the lane that holds it: the 32
+    //      lanes of a half-wave write 32 * NCH consecutive ints.  Otherwise: tiled rows, back through LDS so that they go out
+    //      coalesced.
+    if (b.pack_fused) {
+        if (col < ncols && i + j < c.n) {
+            if (MODE == 1) {
+                int2 *dst = reinterpret_cast<int2 *>(b.res_bm + (size_t)col * c.n * 2) + (i + j);
+                *dst = make_int2(out[0], out[1]);
+            } else {
+                // MODE 0 runs with one channel here (pack_fused: a single coded vector): column = stream-block
+                b.res_bm[(size_t)col * c.n + i + j] = out[0];
+            }
+        }
+        return;
+    }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < NCH; k++) L.in_iw[k][j][g] = out[k];

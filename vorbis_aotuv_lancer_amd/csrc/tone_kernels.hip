@@ -114,6 +114,7 @@ __global__ __launch_bounds__(TM_NB * 32) void k_tonemask(vbm_batch b, const int 
     unsigned short *glS = (unsigned short *)(tm_lds + TM_NB * tnp + (TM_NB & 1));   // [NB][glp]
     const int tid = threadIdx.x;
     const int cb0 = blockIdx.x * TM_NB;
+    if (cb0 >= vbm_ncb(b)) return;                  // (the launch covers the batch's bound; the count lives on the device)
     const int nblk = (vbm_ncb(b) - cb0 < TM_NB) ? vbm_ncb(b) - cb0 : TM_NB;
 
     for (int k = tid; k < TM_NB * tnp; k += TM_THREADS) seedK[k] = seed_key(NEGINF);
@@ -132,8 +133,11 @@ __global__ __launch_bounds__(TM_NB * 32) void k_tonemask(vbm_batch b, const int 
         const int4 *__restrict__ group_tab = (const int4 *)p->group_tab;
         const float *__restrict__ tonecurves = p->tonecurves;
         const int shiftoc = p->shiftoc, firstoc = p->firstoc;
-        for (int item = tid; item < nblk * ngroups; item += TM_THREADS) {
-            const int blk = item / ngroups, g = item - blk * ngroups;
+        // (items = (block, group) pairs dealt round-robin over the threads; block and group advance without a division)
+        int blk = 0, g = tid;
+        while (g >= ngroups) { g -= ngroups; blk++; }
+        for (int item = tid; item < nblk * ngroups; item += TM_THREADS, g += TM_THREADS) {
+            while (g >= ngroups) { g -= ngroups; blk++; }
             const float *f = b.logfft_bm + (size_t)(cb0 + blk) * n;
             const int4 rec = group_tab[g];              // first bin, end bin, ath[last], octave[last]
             const int s0 = rec.x, s1 = rec.y;
@@ -182,8 +186,10 @@ __global__ __launch_bounds__(TM_NB * 32) void k_tonemask(vbm_batch b, const int 
     __syncthreads();
 
     // ---- compare: GE bit k-1 = !(s[j] < s[j-k]), LE bit d-1 = (s[j] <= s[j-d]) ---------------------------------
-    if (phases & 2) for (int item = tid; item < nblk * tn; item += TM_THREADS) {
-        const int blk = item / tn, j = item - blk * tn;
+    int cblk = 0, cj = tid;
+    if (phases & 2) for (int item = tid; item < nblk * tn; item += TM_THREADS, cj += TM_THREADS) {
+        while (cj >= tn) { cj -= tn; cblk++; }
+        const int blk = cblk, j = cj;
         const float *sd = seedF + blk * tnp;
         const float s = sd[j];
         float o[7];
