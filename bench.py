@@ -324,10 +324,11 @@ def main():
         consumer = torch.cuda.Stream(device=dev) if CONSUMER else None
         # rounds per write, cycled: a stream needs ~1.2 blocks per 1024 samples at this signal's block-switching rate
         # (55 long + 10 short + 2 transition blocks per 57 writes), a stream inside a burst eight; streams that fell
-        # behind catch up one extra block per round.  "2,1,1" (1.33 per write) keeps every stream's buffer bounded over
-        # hundreds of writes (300 writes: encoded / input 0.9985, max_buffered_samples_at_end 14528 as after 48);
-        # "2,1,1,1" and "1" do not (the buffers grow until a write is refused, which aborts the run).
-        PATTERN = [int(x) for x in os.environ.get("VBM_BENCH_ROUNDS", "2,1,1").split(",")]
+        # behind catch up one extra block per round.  "2,1,1,1" (1.25 per write) keeps every stream's buffer bounded over
+        # hundreds of writes now that the bursts of the streams are spread evenly over the burst period (320 writes:
+        # encoded / input 0.9985, max_buffered_samples_at_end 16192, as after 96 writes; "2,1,1": 15168, 3 % slower); "1"
+        # does not (the buffers grow until a write is refused, which aborts the run).
+        PATTERN = [int(x) for x in os.environ.get("VBM_BENCH_ROUNDS", "2,1,1,1").split(",")]
 
         def step_pcm(k):
             fe.write(chunks[k])
@@ -583,7 +584,7 @@ def main():
             st = results["pcm"]["stat"]
             line["config"].update({
                 "blocks_encoded": st["blocks"], "rounds": st["rounds"], "rounds_per_write": st["rounds"] / args.steps,
-                "rounds_pattern": os.environ.get("VBM_BENCH_ROUNDS", "2,1,1"),
+                "rounds_pattern": os.environ.get("VBM_BENCH_ROUNDS", "2,1,1,1"),
                 "outputs_joined_on": ("a consumer stream after every call (the feeding stream never waits for packets)"
                                       if os.environ.get("VBM_BENCH_CONSUMER", "1") != "0" else "the feeding stream (lazy join)"),
                 "blocks_by_mode": {"impulse_short": int(st["modes"][0]), "padding_short": int(st["modes"][1]),

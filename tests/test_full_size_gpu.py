@@ -75,7 +75,7 @@ def test_full_size_from_pcm(oracle, cuda, S, K, ch, rate, q, nchunks, multi):
 
 def test_full_size_benchmarked_path(oracle, cuda, monkeypatch):
     """The path bench.py times, at its size: 16384 stereo q5 streams, rounds built on the device replayed as HIP graphs,
-    four workspaces, 2, 1, 1 rounds per 1024-sample write, the feeding stream never tied to the outputs (lazy = 2, a
+    four workspaces, 2, 1, 1, 1 rounds per 1024-sample write (bench.py's default pattern), the feeding stream never tied to the outputs (lazy = 2, a
     consumer stream joins; the first six writes run three rounds each, as the bench's warm-up does, to clear the start of
     the streams where all of them deliver short blocks at once), 64 writes of signals with a noise burst every 40000
     samples (a fifth of the blocks are short ones).  Every stream against its twin (sequence check: a stream may be put off to a later round than its
@@ -91,11 +91,11 @@ def test_full_size_benchmarked_path(oracle, cuda, monkeypatch):
     fe = v.FrontEnd(enc)
     led = TwinLedger(S, K, cuda)
     consumer = torch.cuda.Stream(device=cuda)
-    pattern = (2, 1, 1)
+    pattern = (2, 1, 1, 1)
     for c in range(nchunks):
         chunk = base[:, :, c * 1024:(c + 1) * 1024].repeat(S // K, 1, 1).contiguous()
         fe.write(chunk)
-        info, packets, nbytes, counts = fe.encode_rounds_device(nrounds=3 if c < 6 else pattern[c % 3], lazy=2)
+        info, packets, nbytes, counts = fe.encode_rounds_device(nrounds=3 if c < 6 else pattern[c % 4], lazy=2)
         fe.join(consumer)
         with torch.cuda.stream(consumer):
             led.add_device_rounds(info, packets, nbytes, f"write {c}")

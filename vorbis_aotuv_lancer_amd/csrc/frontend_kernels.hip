@@ -326,20 +326,22 @@ __global__ __launch_bounds__(64) void k_fe_ve_filter(vbm_fe_state f, const vbm_s
     const int nsteps = (last - first < VBM_FE_CHUNK) ? last - first : VBM_FE_CHUNK;
     const int total_it = nsteps * ch;
     // spectrum values of (step t, channel ci): two per lane, three more for lane 0
-    auto spec_of = [&](int it) { return f.ve_spec + (((long)s * ch + it % ch) * VBM_FE_CHUNK + it / ch) * 64; };
+    // (step t and channel ci of an item advance without divisions: it = t * ch + ci)
+    auto spec_of = [&](int t_, int ci_) { return f.ve_spec + (((long)s * ch + ci_) * VBM_FE_CHUNK + t_) * 64; };
     float na = 0.f, nbq = 0.f, na2 = 0.f, nbq2 = 0.f, nh0 = 0.f, nh1 = 0.f, nh2 = 0.f;
-    auto fetch = [&](int it) {
-        const float *sp = spec_of(it);
+    auto fetch = [&](int t_, int ci_) {
+        const float *sp = spec_of(t_, ci_);
         na = sp[2 * jb]; nbq = sp[2 * jb + 1];
         na2 = sp[2 * (jb + 16)]; nbq2 = sp[2 * (jb + 16) + 1];
         if (jb == 0) { nh0 = sp[0]; nh1 = sp[1]; nh2 = sp[2]; }
     };
-    fetch(0);
+    fetch(0, 0);
 
     int ret = 0, stretch = 0;
     float penalty = 0.f;
-    for (int it = 0; it < total_it; it++) {
-        const int t = it / ch, ci = it - t * ch;
+    int t = 0, ci = 0;
+    for (int it = 0; it < total_it; it++, ci++) {
+        if (ci == ch) { ci = 0; t++; }
         const int j = first + t;
         if (ci == 0) {
             ret = 0;
@@ -354,7 +356,7 @@ __global__ __launch_bounds__(64) void k_fe_ve_filter(vbm_fe_state f, const vbm_s
             if (penalty > stretch_penalty) penalty = stretch_penalty;
         }
         const float a = na, bq = nbq, a2 = na2, bq2 = nbq2, h0 = nh0, h1 = nh1, h2 = nh2;
-        if (it + 1 < total_it) fetch(it + 1);
+        if (it + 1 < total_it) fetch(ci + 1 == ch ? t + 1 : t, ci + 1 == ch ? 0 : ci + 1);
 
         float *rc = R + ci * PER_CH;
         float decay = 0.f;
@@ -398,7 +400,7 @@ __global__ __launch_bounds__(64) void k_fe_ve_filter(vbm_fe_state f, const vbm_s
                     if (val < minV) val = minV;
                     s_vec[grp][k] = val;
                 }
-                dk = (float)((double)dk - 8.);
+                dk = dk - 8.f;      // (the source's decay -= 8. in double, rounded back to float: one exact difference, one rounding = the float subtraction)
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -408,7 +410,9 @@ __global__ __launch_bounds__(64) void k_fe_ve_filter(vbm_fe_state f, const vbm_s
         // preecho / postecho triggering by band (:162-559 scalar), one band per lane
         if (band) {
             float acc = 0.f;
-            for (int i = 0; i < end; i++) acc += s_vec[grp][i + begin] * bw[i];
+#pragma unroll
+            for (int i = 0; i < VBM_VE_MAXBAND; i++)          // (unrolled: bw[] stays in registers with static indices)
+                if (i < end) acc += s_vec[grp][i + begin] * bw[i];
             acc *= total;
 
             float *ampbuf = rc + jb;                               // element k at [k * 16]
