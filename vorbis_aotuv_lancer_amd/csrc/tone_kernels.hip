@@ -109,15 +109,14 @@ __global__ __launch_bounds__(TM_NB * 32) void k_tonemask(vbm_batch b, const int 
     const int n = p->n, tn = p->total_octave_lines, linesper = p->eighth_octave_lines;
     const int tnp = tn | 1;                         // odd row pitch of the seed rows
     const int glp = (tn + 8) & ~7;                  // row pitch of the compare bytes
-    int *seedK = tm_lds;                            // [NB][tnp] keys while stamping, floats afterwards
-    float *seedF = (float *)tm_lds;
+    float *seedF = (float *)tm_lds;                 // [NB][tnp] seeds: stamped with the LDS float maximum (ds_max_f32)
     unsigned short *glS = (unsigned short *)(tm_lds + TM_NB * tnp + (TM_NB & 1));   // [NB][glp]
     const int tid = threadIdx.x;
     const int cb0 = blockIdx.x * TM_NB;
     if (cb0 >= vbm_ncb(b)) return;                  // (the launch covers the batch's bound; the count lives on the device)
     const int nblk = (vbm_ncb(b) - cb0 < TM_NB) ? vbm_ncb(b) - cb0 : TM_NB;
 
-    for (int k = tid; k < TM_NB * tnp; k += TM_THREADS) seedK[k] = seed_key(NEGINF);
+    for (int k = tid; k < TM_NB * tnp; k += TM_THREADS) seedF[k] = NEGINF;
     if (tid < TM_NB) {
         const int cb = cb0 + (tid < nblk ? tid : 0);
         float att = b.local_ampmax[cb] + p->ath_adjatt;
@@ -164,7 +163,7 @@ __global__ __launch_bounds__(TM_NB * 32) void k_tonemask(vbm_batch b, const int 
                 const float *curve = posts + 2;
                 const int post1 = (int)posts[1];
                 int seedptr = (int)((float)ocl + (posts[0] - VBM_EHMER_OFFSET) * linesper - (linesper >> 1));
-                int *row = seedK + blk * tnp;
+                float *row = seedF + blk * tnp;
                 // curve values eight at a time ahead of their stamps (table reads are global loads)
                 for (int i = (int)posts[0]; i < post1 && seedptr < tn; i += 8) {
                     float cv[8];
@@ -173,7 +172,8 @@ __global__ __launch_bounds__(TM_NB * 32) void k_tonemask(vbm_batch b, const int 
 #pragma unroll
                     for (int u = 0; u < 8; u++) {
                         if (i + u < post1 && seedptr < tn) {
-                            if (seedptr > 0) atomicMax(&row[seedptr], seed_key(max + cv[u]));
+                            // (ds_max_f32: the maximum of floats is order free; no NaNs, and a sum of two finite floats is never -0)
+                            if (seedptr > 0) (void)__hip_atomic_fetch_max(&row[seedptr], max + cv[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             seedptr += linesper;
                         }
                     }
@@ -181,8 +181,6 @@ __global__ __launch_bounds__(TM_NB * 32) void k_tonemask(vbm_batch b, const int 
             }
         }
     }
-    __syncthreads();
-    for (int k = tid; k < TM_NB * tnp; k += TM_THREADS) seedF[k] = seed_val(seedK[k]);
     __syncthreads();
 
     // ---- compare: GE bit k-1 = !(s[j] < s[j-k]), LE bit d-1 = (s[j] <= s[j-d]) ---------------------------------
