@@ -208,8 +208,13 @@ def load_traffic(ncb):
     tj = json.load(open(tpath))
     if tj.get("channel_blocks_per_step") != ncb:
         return {}, None
-    return tj.get("hbm_bytes_per_launch", {}), {"file": "profiles/pmc_traffic.json", "measured_at": tj.get("commit"),
-                                                "mode": tj.get("mode", "per_block_path")}
+    src = {"file": "profiles/pmc_traffic.json", "measured_at": tj.get("commit"),
+           "mode": "per launch of the step's full-size batch (PMC passes over the per-block leg: every launch there is one such batch)"}
+    if tj.get("from_pcm"):
+        src["from_pcm_total_bytes_per_write"] = tj["from_pcm"].get("total_bytes_per_write")
+    if tj.get("valu_instructions_per_write_from_pcm"):
+        src["valu_instructions_per_write_from_pcm"] = tj["valu_instructions_per_write_from_pcm"]
+    return tj.get("hbm_bytes_per_launch", {}), src
 
 
 def main():
@@ -576,6 +581,18 @@ def main():
             "stage_ms_per_step": per_step,
             "stage_ms_per_launch": per_launch,
         }
+        if traffic_src and traffic_src.get("valu_instructions_per_write_from_pcm") and headline == "pcm":
+            # What bounds the step is instruction issue, not HBM: vector instructions issued per write (PMC,
+            # committed measurement) against what 1024 SIMDs issue per second at one instruction per four cycles
+            n_valu = traffic_src["valu_instructions_per_write_from_pcm"]
+            rate = 256 * 4 * 2.4e9 / 4
+            line["issue_bound"] = {"valu_instructions_per_write": n_valu, "simd_issue_rate_per_s": rate,
+                                   "bound_ms": n_valu / rate * 1e3, "frac_of_step": n_valu / rate * 1e3 / (R["dt"] / args.steps * 1e3),
+                                   "hbm_bytes_per_write": traffic_src.get("from_pcm_total_bytes_per_write"),
+                                   "hbm_frac_of_peak": (traffic_src.get("from_pcm_total_bytes_per_write") or 0) /
+                                                       (R["dt"] / args.steps) / 1e9 / HBM_PEAK_GBPS,
+                                   "source": "profiles/pmc_traffic.json (rocprofv3 --pmc SQ_INSTS_VALU / FETCH_SIZE / WRITE_SIZE over "
+                                             "`bench.py --only pcm`), measured at " + str(traffic_src.get("measured_at"))}
         if "solo" in results:
             line["stage_solo_ms"] = results["solo"]["stage_ms"]
             line["stage_solo_roofline_frac"] = {k: (STAGE_BYTES[k] * ncb / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBPS if ms_ > 0 else None)
