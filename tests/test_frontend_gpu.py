@@ -240,6 +240,14 @@ def test_frontend_output_does_not_depend_on_round_policy(oracle, cuda):
     (1, 11025, 0.5),     # ve_setup_11_uncoupled: one block size (512), one mode
     (1, 8000, 0.5),      # ve_setup_8_uncoupled
     (2, 44100, -0.1),    # q < 0: 512/4096 blocks
+    # round 3: the rest of the reference's test matrix (test/test.c:36-45: 1..8 channels, up to 96 kHz)
+    (3, 44100, 0.5),     # ve_setup_44_uncoupled with 3 .. 8 channels: one submap, residue type 1, a vector per channel
+    (4, 44100, 0.5),
+    (5, 44100, 0.5),
+    (7, 44100, 0.5),
+    (8, 44100, 0.5),
+    (8, 48000, 0.5),     # ve_setup_48_uncoupled
+    (2, 96000, 0.5),     # ve_setup_X_stereo (lib/modes/setup_X.h, lib/vorbisenc.c:185-188)
 ])
 def test_frontend_other_mode_classes_match_oracle(oracle, cuda, ch, rate, q):
     # the 11 kHz and 8 kHz setups have a single block size: only block types 0 and 1 exist

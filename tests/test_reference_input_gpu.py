@@ -54,7 +54,7 @@ def oracle_blocks(oracle, ch, rate, q, pcm):
 
 def test_matrix_is_not_empty():
     cl = classes()
-    assert len(cl) >= 10 and {c[0] for c in cl} == {1, 2, 6}
+    assert len(cl) >= 20 and {c[0] for c in cl} == {1, 2, 3, 4, 5, 6, 7, 8} and 96000 in {c[1] for c in cl}
 
 
 @pytest.mark.parametrize("ch,rate,q", classes())
