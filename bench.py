@@ -413,13 +413,15 @@ def main():
         # kernel by kernel)
         if os.environ.get("VBM_BENCH_NO_STAGE_PASS"):      # kernel traces of the timed region alone (tools/gpu_pcm_trace.sh)
             PROF_STEPS = 0
-        enc.profile_begin(PROF_STEPS * 4)
-        for k in range(PROF_STEPS):
-            step_pcm(args.warmup + args.steps + k)
-        fe.join()
-        torch.cuda.synchronize()
-        blocks_prof = int(v.lib.vbm_encoder_profile_blocks(enc._h))
-        stage_ms, calls = enc.profile_end()
+        blocks_prof, stage_ms, calls = 0, {}, 0
+        if PROF_STEPS:
+            enc.profile_begin(PROF_STEPS * 4)
+            for k in range(PROF_STEPS):
+                step_pcm(args.warmup + args.steps + k)
+            fe.join()
+            torch.cuda.synchronize()
+            blocks_prof = int(v.lib.vbm_encoder_profile_blocks(enc._h))
+            stage_ms, calls = enc.profile_end()
         if DEVICE_ROUNDS:
             modes1, samples1 = end_stats               # totals kept on the device: (blocks per type, samples advanced)
             modes0, samples0 = base_stats[0]
@@ -519,7 +521,7 @@ def main():
             per_step = {k: ms_ / max(r.get("prof_steps", args.steps), 1) for k, ms_ in r["stage_ms"].items()}
             per_launch = {k: ms_ / calls for k, ms_ in r["stage_ms"].items()}
             cb = r["blocks_prof"] * CHANNELS // calls if r["blocks_prof"] else ncb   # channel-blocks per timed launch
-            dominant = max(per_step, key=per_step.get)
+            dominant = max(per_step, key=per_step.get) if per_step else None
             return per_step, per_launch, cb, dominant
 
         if set(results) == {"solo"}:        # (profiling runs: rocprofv3 over the solo launches only)
@@ -542,9 +544,11 @@ def main():
             roofline["kernels"] = STAGE_KERNELS.get(dominant, [])
             roofline["in_situ_ms_per_step"] = per_step.get(dominant)
             roofline["launches_per_step"] = 1
-        else:
+        elif dominant:
             roofline = roof_of(dominant, per_launch[dominant], cb, traffic)
-        if traffic_src:
+        else:
+            roofline = None
+        if traffic_src and roofline:
             roofline["traffic_source"] = traffic_src
         line = {
             "metric": "realtime-stream-equivalents/node (44.1kHz stereo q5) + MDCT HBM GB/s",
