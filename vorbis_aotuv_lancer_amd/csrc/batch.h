@@ -93,6 +93,7 @@ struct vbm_batch {
     int *choice;                    // [Ls] bm->choice of the block
     // Fused packet assembly (k_pack_fused, pack_kernels.hip): one wavefront per stream-block, codewords in LDS.  Setups with
     // one residue submap whose channels form ONE coded vector (stereo coupled res2, mono) on the lane-per-bin couple kernel.
+    int noise_ring;                 // k_noisemask keeps its running sums in a 512-row ring (host-checked window reaches, configure())
     int pack_fused;                 // the batch takes that path (host decision, configure())
     int *res_bm;                    // [nsb][n * ch] quantised residue as the residue coder reads it: bin-interleaved channels
                                     //   (work[x] = in[x % ch][x / ch], lib/res0.c:781-787), written by k_couple_fast

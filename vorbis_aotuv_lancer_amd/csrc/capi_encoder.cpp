@@ -511,6 +511,10 @@ static void configure(vbm_encoder *e, vbm_batch &b, int block_mode, int nsb, con
     }
     b.mix_makes_qf = getenv("VBM_SEPARATE_FLOOR_PREP") ? 0 : vbm_mix_can_make_qf(&b);
     {
+        static const int ring = getenv("VBM_NOISE_RING") ? atoi(getenv("VBM_NOISE_RING")) : 1;
+        b.noise_ring = ring && s->psy[block_mode].hy_ring;
+    }
+    {
         // partition slicing of couple/quantise (quant_kernels.hip): allowed when no channel takes part
         // in two coupling steps; lowpass rounding as lib/mapping0.c:778-781
         const vbm_map &m = s->map[b.W];

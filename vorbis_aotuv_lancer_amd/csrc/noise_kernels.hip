@@ -34,6 +34,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "batch.h"
 #include "kernels.h"
 
@@ -112,6 +113,68 @@ __device__ __forceinline__ void nm_scan(float *__restrict__ q, const int n)
         NM_HALF(ca, cb, k, k + 32)
         NM_HALF(cb, ca, k + 32, k2)
     }
+}
+
+// ---- ring form (round 3): the running sums of a block live in a ring of NM_RING rows per array instead of all n.
+// A window reaches at most ~137 rows ahead of its bin and ~120 behind (bark tables, checked by the host for every setup
+// that takes this path), so bin i can be solved as soon as the scan has passed row i + 137, and rows more than ~380
+// behind the scan are dead.  Per iteration t (one barrier each) three things run side by side in a workgroup:
+//   P  the addends of chunk t + 1 (64 bins) go into the ring            (the compute wavefront that owns those bins)
+//   Q  the scan wavefront (a fifth wavefront, a lane per (block, sum)) carries its sums through chunk t
+//   R  chunk t - NM_LAG is solved from finished rows                    (the compute wavefront that owns those bins)
+// so the latency chain of the scan hides behind the solves of the SAME workgroup instead of waiting for other
+// workgroups to fill the gap, and a block holds 10 KB of LDS instead of 20.
+#define NM_RING 512
+#define NM_RSTR (NM_RING + NM_PAD)
+#define NM_LAG 4
+
+__device__ __forceinline__ void nm_terms_ring(const float v, const int k, const float offset, float *__restrict__ S)
+{
+    float y = v + offset;
+    if (y < 1.f) y = 1.f;
+    float w = y * y;
+    float t1, t2, t4;
+    if (k == 0) {
+        w = (float)((double)w * .5);
+        t1 = w; t2 = 0.f; t4 = 0.f;
+    } else {
+        const float x = (float)k;
+        t1 = w * x; t2 = w * x * x; t4 = w * x * y;
+    }
+    const int r = k & (NM_RING - 1);
+    S[r] = w;
+    S[NM_RSTR + r] = t1;
+    S[2 * NM_RSTR + r] = t2;
+    S[3 * NM_RSTR + r] = w * y;
+    S[4 * NM_RSTR + r] = t4;
+}
+
+__device__ __forceinline__ hy_abd nm_window_ring(const float *__restrict__ S, const int lo, const int hi, const bool mirror)
+{
+    const int l = (mirror ? -lo : lo) & (NM_RING - 1), h = hi & (NM_RING - 1);
+    const float Hn = S[h], Hx = S[NM_RSTR + h], Hxx = S[2 * NM_RSTR + h], Hy = S[3 * NM_RSTR + h], Hxy = S[4 * NM_RSTR + h];
+    const float Ln = S[l], Lx = S[NM_RSTR + l], Lxx = S[2 * NM_RSTR + l], Ly = S[3 * NM_RSTR + l], Lxy = S[4 * NM_RSTR + l];
+    float tN, tX, tXX, tY, tXY;
+    if (mirror) {
+        tN = Hn + Ln; tX = Hx - Lx; tXX = Hxx + Lxx; tY = Hy + Ly; tXY = Hxy - Lxy;
+    } else {
+        tN = Hn - Ln; tX = Hx - Lx; tXX = Hxx - Lxx; tY = Hy - Ly; tXY = Hxy - Lxy;
+    }
+    hy_abd r;
+    r.A = tY * tXX - tX * tXY;
+    r.B = tN * tXY - tX * tY;
+    r.D = tN * tXX - tX * tX;
+    return r;
+}
+
+// one lane: the running sum carried through 64 more addends, in place (q = the chunk's first row)
+__device__ __forceinline__ void nm_scan_chunk(float *__restrict__ q, float &acc)
+{
+    float4 ca[8], cb[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) ca[u] = *reinterpret_cast<float4 *>(q + 4 * u);
+    NM_HALF(ca, cb, 0, 32)
+    NM_HALF(cb, ca, 32, 0)      // (the second fetch re-reads finished rows: nothing waits for it)
 }
 
 // aoTuV M7, lib/psy.c:3645-3768, on LDS rows: spectral = logmdct, noise = pass 2's logmdct - work; temp / inmod: 256 each
@@ -233,10 +296,10 @@ __device__ __forceinline__ void put_row(float *__restrict__ q, const float *v, c
 }
 
 // ROWS = ceil(n / 256): thread t holds bins t, t + 256, ... of all NB blocks
-template <int NB, int ROWS>
-__global__ __launch_bounds__(NM_THREADS) void k_noisemask(vbm_batch b, const int phases)
+template <int NB, int ROWS, bool RING>
+__global__ __launch_bounds__(NM_THREADS + (RING ? 64 : 0)) void k_noisemask(vbm_batch b, const int phases)
 {
-    extern __shared__ __align__(16) float SU[];      // [NB][5][NS] addends, then running sums; later rows for M7 / M2 / M8
+    extern __shared__ __align__(16) float SU[];      // [NB][5][NS] addends, then running sums (RING: [NB][5][NM_RSTR]); later rows for M7 / M2 / M8
     __shared__ float s_ncl[NB], s_poste[NB];
     __shared__ int s_col[NB], s_need[NB];
 
@@ -252,6 +315,8 @@ __global__ __launch_bounds__(NM_THREADS) void k_noisemask(vbm_batch b, const int
     if (lane0 >= ncb) return;
     const int nb = VMIN(NB, ncb - lane0);
     const int tid = (int)threadIdx.x;
+    const bool scanw = RING && tid >= NM_THREADS;      // the scan wavefront of the ring form
+    const int BS = RING ? 5 * NM_RSTR : 5 * NS;        // floats of LDS per block
 
     const int i1 = p->hy_i1, i2 = p->hy_i2;
     const int fixed = p->noisewindowfixed;
@@ -262,7 +327,7 @@ __global__ __launch_bounds__(NM_THREADS) void k_noisemask(vbm_batch b, const int
     int wlo[ROWS], whi[ROWS];        // the variable window of the thread's bins (bins from i2 on: that of bin i2 - 1)
 
     // ---- logmdct (lib/mapping0.c:936-950)
-    {
+    if (!scanw) {
         const float *__restrict__ src = b.mdct_bm + (size_t)lane0 * n;
         const int *__restrict__ bark_lo = p->bark_lo, *__restrict__ bark_hi = p->bark_hi;
 #pragma unroll
@@ -288,7 +353,7 @@ __global__ __launch_bounds__(NM_THREADS) void k_noisemask(vbm_batch b, const int
     // ---- lb_loudnoise_fix (lib/psy.c:5152-5180); the mean over the middle bins is a double-precision chain in bin
     //      order: a block that needs it (the first block after a change between transition and long blocks) has its
     //      logmdct row put into LDS for one lane to walk
-    if (tid < nb) {
+    if (!scanw && tid < nb) {
         const int lane = lane0 + tid;
         const int sb = lane / b.ch, c = lane - sb * b.ch;
         const int sid = b.stream_id[sb];
@@ -309,19 +374,20 @@ __global__ __launch_bounds__(NM_THREADS) void k_noisemask(vbm_batch b, const int
         int any = 0;
         for (int blk = 0; blk < nb; blk++) any |= s_need[blk];
         if (any) {      // (uniform over the workgroup)
+            if (!scanw)
 #pragma unroll
             for (int r = 0; r < ROWS; r++) {
                 const int i = tid + r * NM_THREADS;
                 if (i < n)
 #pragma unroll
                     for (int blk = 0; blk < NB; blk++)
-                        if (blk < nb) SU[(size_t)blk * 5 * NS + i] = lm[r][blk];
+                        if (blk < nb) SU[(size_t)blk * BS + i] = lm[r][blk];
             }
             __syncthreads();
-            if (tid < nb && s_need[tid]) {
+            if (!scanw && tid < nb && s_need[tid]) {
                 double hi_th = 0;
                 const int n25p = p->n25p, n75p = p->n75p;
-                const float *row = SU + (size_t)tid * 5 * NS;
+                const float *row = SU + (size_t)tid * BS;
                 for (int k = n25p; k < n75p; k++) {
                     const float v = row[k];
                     hi_th += (v > -130) ? (double)v : -130.;
@@ -336,9 +402,88 @@ __global__ __launch_bounds__(NM_THREADS) void k_noisemask(vbm_batch b, const int
             __syncthreads();
         }
     }
-    if (tid < nb) b.st.lowcomp[s_col[tid]] = s_ncl[tid];
+    if (!scanw && tid < nb) b.st.lowcomp[s_col[tid]] = s_ncl[tid];
 
     // ---- the two passes of bark_noise_hybridmp (lib/psy.c:3799-3812)
+    if constexpr (RING) {
+        const int NCH = n >> 6;                          // chunks of 64 bins (n is a multiple of 256 here)
+        const int wv = tid >> 6, ln = tid & 63;
+        // the scan wavefront: lane L = (block, sum)
+        const int sblk = ln / 5, ssum = ln - sblk * 5;
+        const bool slive = scanw && ln < nb * 5;
+        float *const sq = SU + (size_t)sblk * BS + ssum * NM_RSTR;
+#pragma unroll 1
+        for (int pass = 1; pass <= 2; pass++) {
+            const float offset = (pass == 1) ? 140.f : 0.f;
+            float sacc = 0.f;
+            // the solve of bin i = tid + 256 r, r a compile-time constant (the bin's values live in registers lm[r] / wk[r] / nz[r])
+            auto solve = [&](auto RC) {
+                constexpr int r = decltype(RC)::value;
+                const int i = tid + r * NM_THREADS;
+                const float x = (float)i;
+                const bool have = i2 > 0;
+                const bool mirror = ((i < i2) ? i : i2 - 1) < i1;
+                const int fw = (i < f2) ? i : f2 - 1;
+                const int fhi = fw + fixed / 2, flo = fhi - fixed;
+#pragma unroll
+                for (int blk = 0; blk < NB; blk++) {
+                    if (blk >= nb) continue;
+                    const float *S = SU + (size_t)blk * BS;
+                    hy_abd v; v.A = 0.f; v.B = 0.f; v.D = 1.f;
+                    if (have) v = nm_window_ring(S, wlo[r], whi[r], mirror);
+                    float R = (v.A + x * v.B) / v.D;
+                    if (R < 0.f) R = 0.f;
+                    float nzv = R - offset;
+                    if (pass == 1) {
+                        wk[r][blk] = lm[r][blk] - nzv;                     // lib/psy.c:3807
+                    } else {
+                        if (fixed > 0) {
+                            hy_abd w = v;
+                            if (fw >= 0) w = nm_window_ring(S, flo, fhi, fw < f1);
+                            else if (i < i2 && have) w = nm_window_ring(S, p->bark_lo[i2 - 1], p->bark_hi[i2 - 1], i2 - 1 < i1);
+                            R = (w.A + x * w.B) / w.D;
+                            if (R - offset < nzv) nzv = R - offset;
+                        }
+                        nz[r][blk] = nzv;
+                        wk[r][blk] = lm[r][blk] - wk[r][blk];              // lib/psy.c:3812
+                    }
+                }
+            };
+            auto terms = [&](auto RC) {
+                constexpr int r = decltype(RC)::value;
+                const int i = tid + r * NM_THREADS;
+#pragma unroll
+                for (int blk = 0; blk < NB; blk++)
+                    if (blk < nb) nm_terms_ring(pass == 1 ? lm[r][blk] : wk[r][blk], i, offset, SU + (size_t)blk * BS);
+            };
+#pragma unroll 1
+            for (int t = -1; t < NCH + NM_LAG; t++) {
+                if (!scanw) {
+                    const int cp = t + 1, cr = t - NM_LAG;
+                    if (cp < NCH && (cp & 3) == wv) {               // P: the addends of chunk t + 1
+                        switch (cp >> 2) {
+                        case 0: terms(std::integral_constant<int, 0>{}); break;
+                        case 1: if constexpr (ROWS > 1) terms(std::integral_constant<int, 1>{}); break;
+                        case 2: if constexpr (ROWS > 2) terms(std::integral_constant<int, 2>{}); break;
+                        case 3: if constexpr (ROWS > 3) terms(std::integral_constant<int, 3>{}); break;
+                        }
+                    }
+                    if (cr >= 0 && cr < NCH && (cr & 3) == wv && (phases & 2)) {   // R: chunk t - NM_LAG from finished rows
+                        switch (cr >> 2) {
+                        case 0: solve(std::integral_constant<int, 0>{}); break;
+                        case 1: if constexpr (ROWS > 1) solve(std::integral_constant<int, 1>{}); break;
+                        case 2: if constexpr (ROWS > 2) solve(std::integral_constant<int, 2>{}); break;
+                        case 3: if constexpr (ROWS > 3) solve(std::integral_constant<int, 3>{}); break;
+                        }
+                    }
+                } else if (slive && t >= 0 && t < NCH && (phases & 1)) {
+                    nm_scan_chunk(sq + ((t << 6) & (NM_RING - 1)), sacc);   // Q: the sums through chunk t
+                }
+                __syncthreads();
+            }
+        }
+        if (scanw) return;      // the scan wavefront is done (a wavefront that has ended is not waited for at later barriers)
+    } else
 #pragma unroll
     for (int pass = 1; pass <= 2; pass++) {
         const float offset = (pass == 1) ? 140.f : 0.f;
@@ -404,13 +549,13 @@ __global__ __launch_bounds__(NM_THREADS) void k_noisemask(vbm_batch b, const int
 #pragma unroll
                 for (int blk = 0; blk < NB; blk++)
                     if (blk < nb) {
-                        SU[(size_t)blk * 5 * NS + i] = lm[r][blk];
-                        SU[(size_t)blk * 5 * NS + NS + i] = wk[r][blk];
+                        SU[(size_t)blk * BS + i] = lm[r][blk];
+                        SU[(size_t)blk * BS + NS + i] = wk[r][blk];
                     }
         }
         __syncthreads();
         if (tid < nb) {
-            float *row = SU + (size_t)tid * 5 * NS;
+            float *row = SU + (size_t)tid * BS;
             nm_ntfix(p, b.block_mode, row, row + NS, row + 2 * NS, row + 2 * NS + scratch, scratch);
         }
         __syncthreads();
@@ -420,7 +565,7 @@ __global__ __launch_bounds__(NM_THREADS) void k_noisemask(vbm_batch b, const int
             if (i < n)
 #pragma unroll
                 for (int blk = 0; blk < NB; blk++)
-                    if (blk < nb) wk[r][blk] = SU[(size_t)blk * 5 * NS + NS + i];
+                    if (blk < nb) wk[r][blk] = SU[(size_t)blk * BS + NS + i];
         }
         __syncthreads();
     }
@@ -429,7 +574,8 @@ __global__ __launch_bounds__(NM_THREADS) void k_noisemask(vbm_batch b, const int
     //      every bin's peak by a value of that peak, logmdct and lastmdct alone); logmdct and epeak rows go out, logmdct
     //      and logmask go to LDS for the partitions' lanes (row of partition k shifted by k words)
     const int partition = (p->normal_p ? p->normal_partition : 16);
-    const int SK = 2 * NS;           // logmask rows start here (a skewed row is n + n / partition <= 2 NS words)
+    // logmask rows start here (a skewed row is n + n / partition <= 2 NS words; the ring form has 5 * NM_RSTR words per block)
+    const int SK = RING ? n + n / partition + 4 : 2 * NS;
     {
         const float *__restrict__ noisecompand = p->noisecompand, *__restrict__ noisecompand_high = p->noisecompand_high;
         const int *__restrict__ stn_compand = s->stn_compand;
@@ -468,8 +614,8 @@ __global__ __launch_bounds__(NM_THREADS) void k_noisemask(vbm_batch b, const int
                         }
                     }
                     epv[blk] = e;
-                    SU[(size_t)blk * 5 * NS + sk] = lmd;
-                    SU[(size_t)blk * 5 * NS + SK + sk] = lk;
+                    SU[(size_t)blk * BS + sk] = lmd;
+                    SU[(size_t)blk * BS + SK + sk] = lk;
                 }
             }
             if (phases & 16) {
@@ -489,8 +635,8 @@ __global__ __launch_bounds__(NM_THREADS) void k_noisemask(vbm_batch b, const int
         for (int t = tid; t < nb * nparts; t += NM_THREADS) {
             const int blk = t / nparts, k = t - blk * nparts;
             const int i = k * partition;
-            const float *logmdct = SU + (size_t)blk * 5 * NS + i + k;
-            float *logmask = SU + (size_t)blk * 5 * NS + SK + i + k;
+            const float *logmdct = SU + (size_t)blk * BS + i + k;
+            float *logmask = SU + (size_t)blk * BS + SK + i + k;
             float np = 0.f;
             if (i < min_nn_lp) {
                 const float poste = s_poste[blk];
@@ -531,24 +677,24 @@ __global__ __launch_bounds__(NM_THREADS) void k_noisemask(vbm_batch b, const int
             const int sk = i + i / partition;
             float v[NB];
 #pragma unroll
-            for (int blk = 0; blk < NB; blk++) v[blk] = (blk < nb) ? SU[(size_t)blk * 5 * NS + SK + sk] : 0.f;
+            for (int blk = 0; blk < NB; blk++) v[blk] = (blk < nb) ? SU[(size_t)blk * BS + SK + sk] : 0.f;
             put_row<NB>(noiseT + (size_t)i * 64, v, nb);
         }
     }
 }
 
-template <int NB, int ROWS>
+template <int NB, int ROWS, bool RING = false>
 int launch(const vbm_batch *b, hipStream_t st)
 {
     // (called from several host threads at once: one-time set-up through initialisers of function-local statics)
     static const int phases = getenv("VBM_NOISE_PHASES") ? atoi(getenv("VBM_NOISE_PHASES")) : 31;   // timing experiments
-    size_t lds = (size_t)5 * NB * (b->n + NM_PAD) * sizeof(float);
+    size_t lds = (size_t)5 * NB * (RING ? NM_RSTR : b->n + NM_PAD) * sizeof(float);
     if (getenv("VBM_NOISE_LDS_PAD")) lds += (size_t)atoi(getenv("VBM_NOISE_LDS_PAD")) * 1024;   // occupancy experiments
-    static const bool attr = hipFuncSetAttribute(reinterpret_cast<const void *>(k_noisemask<NB, ROWS>),
+    static const bool attr = hipFuncSetAttribute(reinterpret_cast<const void *>(k_noisemask<NB, ROWS, RING>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
     (void)attr;
     const unsigned wgs = (unsigned)((b->ncb + NB - 1) / NB);
-    hipLaunchKernelGGL((k_noisemask<NB, ROWS>), dim3((wgs + 7u) & ~7u), dim3(NM_THREADS), lds, st, *b, phases);
+    hipLaunchKernelGGL((k_noisemask<NB, ROWS, RING>), dim3((wgs + 7u) & ~7u), dim3(NM_THREADS + (RING ? 64 : 0)), lds, st, *b, phases);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -562,6 +708,7 @@ extern "C" int vbm_launch_noisemask(const vbm_batch *b, hipStream_t st)
     if ((n & 63) || n < 128 || n > 4096) return -2;     // (M7's scratch rows live in a block's five sum arrays)
     if (n <= 256) return launch<8, 1>(b, st);
     if (n <= 512) return launch<4, 2>(b, st);
+    if (n == 1024 && b->noise_ring) return launch<2, 4, true>(b, st);     // ring form: host-checked window reaches (configure())
     if (n <= 1024) return launch<2, 4>(b, st);
     return launch<1, 16>(b, st);
 }

@@ -45,6 +45,7 @@ struct vbm_psy {                 // vorbis_info_psy + vorbis_look_psy
     int hy_i1, hy_i2;                // bark_noise_hybridmp phase limits, variable window (lib/psy.c:3543, :3565)
     int hy_rb;                       // rows [0, hy_rb) of the running sums are read directly (mirrored window edges): multiple of 16
     int hy_f1, hy_f2;                // same for the fixed window of noisewindowfixed (:3595, :3614); 0 if unused
+    int hy_ring;                     // 1: every window of every bin fits the 512-row ring schedule of k_noisemask<.., RING> (setup_host.cpp)
     const float *tonecurves;         // [P_BANDS][P_LEVELS][EHMER_MAX+2]
     const float *noiseoffset[VBM_P_NOISECURVES];  // n each
     const float *ath;                // n

@@ -735,6 +735,32 @@ vbm_setup_host *vbm_setup_host_load(const char *common_path, const char *mode_pa
                 }
                 p.hy_rb = (rb + 15) & ~15;
                 if (p.hy_rb > n) p.hy_rb = n;
+                // ring form of the noise mask kernel (noise_kernels.hip, NM_RING = 512 rows, NM_LAG = 4, chunks of 64 bins):
+                // bin i of chunk c = i / 64 is solved in iteration c + 4, when the sums are final through chunk c + 3 and
+                // the addends of chunk min(c + 5, last) have overwritten chunk min(c + 5, last) - 8.  Every row a bin reads
+                // (both edges of the variable window, of the fixed window, mirrored or not; bins past the loop limits keep
+                // the window of the last bin inside them) has to lie between the two.
+                {
+                    const int nch = n / 64;
+                    bool ok = (n == 1024) && p.hy_i2 > 0 && (fixed <= 0 || p.hy_f2 > 0);
+                    auto row_ok = [&](int i, int row) {
+                        const int c = i >> 6, rc = row >> 6;
+                        const int done = (c + 3 < nch - 1) ? c + 3 : nch - 1;
+                        const int dead = ((c + 5 < nch - 1) ? c + 5 : nch - 1) - 8;
+                        return row >= 0 && row < n && rc <= done && rc > dead;
+                    };
+                    for (k = 0; k < n && ok; k++) {
+                        const int iw = (k < p.hy_i2) ? k : p.hy_i2 - 1;
+                        const int lo = t.bark_lo[iw], hi = t.bark_hi[iw];
+                        ok = ok && row_ok(k, hi) && row_ok(k, iw < p.hy_i1 ? -lo : lo);
+                        if (fixed > 0) {
+                            const int fw = (k < p.hy_f2) ? k : p.hy_f2 - 1;
+                            const int fhi = fw + fixed / 2, flo = fhi - fixed;
+                            ok = ok && row_ok(k, fhi) && row_ok(k, fw < p.hy_f1 ? -flo : flo);
+                        }
+                    }
+                    p.hy_ring = ok ? 1 : 0;
+                }
             }
         }
 
