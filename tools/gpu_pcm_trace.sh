@@ -5,7 +5,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/pcmtrace
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export VBM_BENCH_NO_STAGE_PASS=1
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s -- python3 $GRAFT_REPO_ROOT/bench.py --only pcm --steps ${STEPS:-12} --warmup 4 --no-cpu-baseline > $OUT/stats.log 2>&1; echo "stats rc=$?"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s -- python3 $GRAFT_REPO_ROOT/bench.py ${BENCH_EXTRA} --only pcm --steps ${STEPS:-12} --warmup 4 --no-cpu-baseline > $OUT/stats.log 2>&1; echo "stats rc=$?"
 DB=$(ls $OUT/stats/*/*.db $OUT/stats/*.db 2>/dev/null | head -1)
 python3 $GRAFT_REPO_ROOT/tools/kstats.py $DB > $OUT/kstats.txt 2>&1
 python3 $GRAFT_REPO_ROOT/tools/ktimeline.py $DB ${LAST:-700} > $OUT/timeline.txt 2>&1

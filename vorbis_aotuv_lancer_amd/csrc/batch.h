@@ -91,6 +91,20 @@ struct vbm_batch {
     uint8_t *packetT_blob;          // [PACKETBLOBS] packet tiles, each laid out like packetT
     int *packet_bytes_blob;         // [PACKETBLOBS][Ls]
     int *choice;                    // [Ls] bm->choice of the block
+    // Round 3: the back half of a managed block runs ALL its packetblobs per launch (blob = blockIdx.z of the floor encode /
+    // render, M6 statistics and packet kernels; k_couple_fast walks the blobs in a loop of its own because blob k reads the
+    // npeak rows as blobs 0..k-1 left them, lib/mapping0.c:1249-1260).  Every array the back half writes exists once per blob
+    // (blob-major copies with the same inner layout); vbm_blob_select() points the single-blob names above at blob k.
+    int nblobs;                     // 1 (VBR, or a host loop over the blobs), or VBM_PACKETBLOBS
+    int *floor_outT_blob, *iworkT_blob;     // tile slab: blob k at + k * rows * 64 (rows: VIF_POSIT+2, blob_iwork_rows)
+    int blob_iwork_rows;
+    int *nonzero_blob;              // [nblobs][L]
+    int *packet_bits_blob;          // [nblobs][Ls]
+    int *partwordT_blob, *vqlenT_blob, *vqoffT_blob;    // stream-block slab: blob k at + k * rows * 64
+    float *m6defT_blob;
+    int blob_pw_rows, blob_m6_rows, blob_len_rows;
+    uint64_t *vqcodeT_blob;         // blob k at + k * vq_blob_words
+    size_t vq_blob_words;
     // Fused packet assembly (k_pack_fused, pack_kernels.hip): one wavefront per stream-block, codewords in LDS.  Setups with
     // one residue submap whose channels form ONE coded vector (stereo coupled res2, mono) on the lane-per-bin couple kernel.
     int noise_ring;                 // k_noisemask keeps its running sums in a 512-row ring (host-checked window reaches, configure())
@@ -104,7 +118,35 @@ struct vbm_batch {
     int pack_spp[16];               // samples per partition (residue grouping) of each submap
 };
 
+// the single-blob names of a managed batch pointed at packetblob k (host: loops over the blobs; device: vbm_blob_enter)
+static inline
 #ifdef __HIPCC__
+__host__ __device__
+#endif
+void vbm_blob_select(vbm_batch &b, int k)
+{
+    b.blobno = k;
+    b.postT = b.postT_blob + (size_t)k * (VBM_VIF_POSIT + 2) * 64;
+    b.post_valid = b.post_valid_blob + (size_t)k * b.L;
+    b.floor_outT = b.floor_outT_blob + (size_t)k * (VBM_VIF_POSIT + 2) * 64;
+    b.iworkT = b.iworkT_blob + (size_t)k * b.blob_iwork_rows * 64;
+    b.nonzero = b.nonzero_blob + (size_t)k * b.L;
+    b.packetT = b.packetT_blob + (size_t)k * b.Ls * b.max_packet_bytes;
+    b.packet_bytes = b.packet_bytes_blob + (size_t)k * b.Ls;
+    b.packet_bits = b.packet_bits_blob + (size_t)k * b.Ls;
+    b.partwordT = b.partwordT_blob + (size_t)k * b.blob_pw_rows * 64;
+    b.m6defT = b.m6defT_blob + (size_t)k * b.blob_m6_rows * 64;
+    b.vqlenT = b.vqlenT_blob + (size_t)k * b.blob_len_rows * 64;
+    b.vqoffT = b.vqoffT_blob + (size_t)k * b.blob_len_rows * 64;
+    b.vqcodeT = b.vqcodeT_blob + (size_t)k * b.vq_blob_words;
+}
+
+#ifdef __HIPCC__
+// first statement of a back-half kernel that runs a blob per blockIdx.z
+__device__ __forceinline__ void vbm_blob_enter(vbm_batch &b)
+{
+    if (b.nblobs > 1) vbm_blob_select(b, (int)blockIdx.z);
+}
 __device__ __forceinline__ int vbm_nsb(const vbm_batch &b) { return b.d_nsb ? *b.d_nsb : b.nsb; }
 __device__ __forceinline__ int vbm_ncb(const vbm_batch &b) { return vbm_nsb(b) * b.ch; }
 // lib/scales.h:43-51

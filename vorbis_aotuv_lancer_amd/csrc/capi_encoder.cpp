@@ -292,6 +292,8 @@ extern "C" int vbm_encoder_create(vbm_encoder **out, vbm_setup_handle *setup, in
       if (e->nws < 2) e->nws = 2;
       if (e->nws > kMaxWS) e->nws = kMaxWS;
   }
+  // managed bitrate: every array the back half writes exists once per packetblob (batch.h, vbm_blob_select)
+  const size_t NBL = s->managed ? VBM_PACKETBLOBS : 1;
   for (int w = 0; w < e->nws; w++) {
     vbm_batch &b = e->bw[w];
     e->ws_alloc[w] = e->allocs.size();
@@ -317,7 +319,7 @@ extern "C" int vbm_encoder_create(vbm_encoder **out, vbm_setup_handle *setup, in
         const size_t o_mdct = take(nmax), o_logmdct = take(nmax), o_noise = take(nmax),
                      o_tone = take(nmax), o_logmask = take(nmax), o_epeak = take(nmax),
                      o_npeak = take(nmax / 8 + 1), o_post = take((size_t)(VBM_VIF_POSIT + 2) * VBM_PACKETBLOBS),
-                     o_fout = take(VBM_VIF_POSIT + 2), o_iwork = take(nmax);
+                     o_fout = take((size_t)(VBM_VIF_POSIT + 2) * NBL), o_iwork = take((size_t)nmax * NBL);
         b.slab_words = rows * 64;
         float *slab;
         A(slab, float, (L / 64) * b.slab_words);
@@ -327,6 +329,8 @@ extern "C" int vbm_encoder_create(vbm_encoder **out, vbm_setup_handle *setup, in
         b.postT_blob = (int *)(slab + o_post);
         b.postT = b.postT_blob + (size_t)(VBM_PACKETBLOBS / 2) * (VBM_VIF_POSIT + 2) * 64;
         b.floor_outT = (int *)(slab + o_fout); b.iworkT = (int *)(slab + o_iwork);
+        b.floor_outT_blob = b.floor_outT; b.iworkT_blob = b.iworkT;
+        b.blob_iwork_rows = nmax;
 
         size_t srows = 0;
         auto stake = [&](size_t r) { size_t at = srows; srows += r; return at * 64; };
@@ -334,13 +338,15 @@ extern "C" int vbm_encoder_create(vbm_encoder **out, vbm_setup_handle *setup, in
         for (int i = 0; i < s->modes && i < 2; i++)
             if (s->map[i].coupling_steps > max_steps) max_steps = s->map[i].coupling_steps;
         // (the residue VQ stages its partitions in LDS: no interleaved copy of the residue in HBM any more)
-        const size_t o_pw = stake((size_t)e->max_partvals * e->ch), o_vq = stake(1),
-                     o_m6 = stake((size_t)(nmax / 8 + 1) * max_steps);
+        b.blob_pw_rows = e->max_partvals * e->ch;
+        b.blob_m6_rows = (nmax / 8 + 1) * max_steps;
+        const size_t o_pw = stake((size_t)b.blob_pw_rows * NBL), o_vq = stake(1),
+                     o_m6 = stake((size_t)b.blob_m6_rows * NBL);
         int max_stages = 1;
         for (int i = 0; i < s->residues; i++)
             if (s->residue[i].stages > max_stages) max_stages = s->residue[i].stages;
-        const size_t o_len = stake((size_t)max_stages * e->ch * e->max_partvals),
-                     o_off = stake((size_t)max_stages * e->ch * e->max_partvals);
+        b.blob_len_rows = max_stages * e->ch * e->max_partvals;
+        const size_t o_len = stake((size_t)b.blob_len_rows * NBL), o_off = stake((size_t)b.blob_len_rows * NBL);
         b.sb_slab_words = srows * 64;
         int *sslab;
         A(sslab, int, (Ls / 64) * b.sb_slab_words);
@@ -350,13 +356,18 @@ extern "C" int vbm_encoder_create(vbm_encoder **out, vbm_setup_handle *setup, in
         b.vqlenT = sslab + o_len;
         b.vqoffT = sslab + o_off;
         b.vq_slab_words = (size_t)max_stages * nmax * e->ch * 64;
-        A(b.vqcodeT, uint64_t, (Ls / 64) * b.vq_slab_words);
+        b.vq_blob_words = (Ls / 64) * b.vq_slab_words;
+        A(b.vqcodeT, uint64_t, b.vq_blob_words * NBL);
+        b.partwordT_blob = b.partwordT; b.m6defT_blob = b.m6defT; b.vqlenT_blob = b.vqlenT; b.vqoffT_blob = b.vqoffT;
+        b.vqcodeT_blob = b.vqcodeT;
     }
     A(b.poste, float, L);
     A(b.global_ampmax, float, Ls);
     A(b.post_valid_blob, int, L * VBM_PACKETBLOBS);
     b.post_valid = b.post_valid_blob + (size_t)(VBM_PACKETBLOBS / 2) * L;
-    A(b.nonzero, int, L);
+    A(b.nonzero, int, L * NBL);
+    b.nonzero_blob = b.nonzero;
+    b.nblobs = 1;
     A(b.packetT, uint8_t, Ls * (size_t)e->max_packet_bytes);   // [sb>>6][max_packet_bytes][64]
     A(b.packet_bytes, int, Ls);
     if (s->managed) {   // one packet buffer per packetblob (lib/mapping0.c:1204)
@@ -364,7 +375,8 @@ extern "C" int vbm_encoder_create(vbm_encoder **out, vbm_setup_handle *setup, in
         A(b.packet_bytes_blob, int, Ls * VBM_PACKETBLOBS);
         A(b.choice, int, Ls);
     }
-    A(b.packet_bits, int, Ls);
+    A(b.packet_bits, int, Ls * NBL);
+    b.packet_bits_blob = b.packet_bits;
     b.stream_id = e->d_stream_id[w];
     b.wflags = e->d_wflags[w];
     e->ws_alloc[w + 1] = e->allocs.size();
@@ -511,7 +523,10 @@ static void configure(vbm_encoder *e, vbm_batch &b, int block_mode, int nsb, con
     }
     b.mix_makes_qf = getenv("VBM_SEPARATE_FLOOR_PREP") ? 0 : vbm_mix_can_make_qf(&b);
     {
-        static const int ring = getenv("VBM_NOISE_RING") ? atoi(getenv("VBM_NOISE_RING")) : 1;
+        // opt-in (VBM_NOISE_RING=1): measured slower than the plain form — alone 0.93 ms against 0.73, from PCM 5.10 ms per
+        // step against 4.51 (profiles/r03/README.md): a barrier per 64-bin chunk puts the scan's chunk on every iteration's
+        // critical path, and seven workgroups of five wavefronts per CU do not make up for it
+        static const int ring = getenv("VBM_NOISE_RING") ? atoi(getenv("VBM_NOISE_RING")) : 0;
         b.noise_ring = ring && s->psy[block_mode].hy_ring;
     }
     {
@@ -576,16 +591,18 @@ static vbm_batch slice_of(const vbm_batch &f, int sb0, int nsb, uint8_t *d_packe
     v.stream_id += sb0; v.wflags += sb0;
     v.pcm += cb0 * f.N; v.mdct_bm += cb0 * f.n; v.logfft_bm += cb0 * f.n; v.qf_bm += cb0 * f.n; v.res_bm += cb0 * f.n;
     v.local_ampmax += cb0; v.wflags_cb += cb0; v.poste += cb0; v.post_valid += cb0; v.nonzero += cb0;
-    v.post_valid_blob += cb0;
-    v.global_ampmax += sb0; v.packet_bytes += sb0; v.packet_bits += sb0;
+    v.post_valid_blob += cb0; v.nonzero_blob += cb0;
+    v.global_ampmax += sb0; v.packet_bytes += sb0; v.packet_bits += sb0; v.packet_bits_blob += sb0;
     if (v.packet_bytes_blob) { v.packet_bytes_blob += sb0; v.choice += sb0; v.packetT_blob += stl * 64 * (size_t)f.max_packet_bytes; }
     const size_t co = ct * f.slab_words;
     v.mdctT += co; v.logmdctT += co; v.noiseT += co; v.toneT += co; v.logmaskT += co;
     v.epeakT += co; v.npeakT += co;
     v.postT += co; v.postT_blob += co; v.floor_outT += co; v.iworkT += co;
+    v.floor_outT_blob += co; v.iworkT_blob += co;
     const size_t so = stl * f.sb_slab_words;
     v.partwordT += so; v.workvqT += so; v.m6defT += so; v.vqlenT += so; v.vqoffT += so;
-    v.vqcodeT += stl * f.vq_slab_words;
+    v.partwordT_blob += so; v.m6defT_blob += so; v.vqlenT_blob += so; v.vqoffT_blob += so;
+    v.vqcodeT += stl * f.vq_slab_words; v.vqcodeT_blob += stl * f.vq_slab_words;
     v.packetT += stl * 64 * (size_t)f.max_packet_bytes;
     return v;
 }
@@ -610,13 +627,30 @@ static int managed_front(const vbm_batch &v, hipStream_t q)
 // (lib/bitrate.c:98-252): choice, final lengths, the chosen packets
 static int managed_back(const vbm_batch &v, uint8_t *d_packets, hipStream_t q)
 {
+    static const int wide = getenv("VBM_MANAGED_WIDE") ? atoi(getenv("VBM_MANAGED_WIDE")) : 1;
+    if (wide) {
+        // all fifteen packetblobs per launch (blob = blockIdx.z); the blobs' coupling passes form a chain through the npeak
+        // rows (lib/mapping0.c:1249-1260, lib/psy.c:5100-5108): the lane-per-bin kernel walks them in a loop of its own, the
+        // general kernel is launched once per blob
+        vbm_batch f = v;
+        f.nblobs = VBM_PACKETBLOBS;
+        vbm_blob_select(f, 0);
+        if (vbm_launch_floor_encode(&f, q)) return -2;
+        if (f.couple_fast) {
+            if (vbm_launch_couple_quantize(&f, q)) return -2;
+        } else {
+            for (int k = 0; k < VBM_PACKETBLOBS; k++) {
+                vbm_batch g = v;
+                vbm_blob_select(g, k);
+                if (vbm_launch_couple_quantize(&g, q)) return -2;
+            }
+        }
+        if (vbm_launch_pack(&f, q)) return -2;
+        return vbm_launch_bitrate_choose(&v, d_packets, q);
+    }
     for (int k = 0; k < VBM_PACKETBLOBS; k++) {
         vbm_batch f = v;
-        f.blobno = k;
-        f.postT = v.postT_blob + (size_t)k * (VBM_VIF_POSIT + 2) * 64;
-        f.post_valid = v.post_valid_blob + (size_t)k * v.L;
-        f.packetT = v.packetT_blob + (size_t)k * v.Ls * v.max_packet_bytes;
-        f.packet_bytes = v.packet_bytes_blob + (size_t)k * v.Ls;
+        vbm_blob_select(f, k);
         if (vbm_launch_floor_encode(&f, q) || vbm_launch_couple_quantize(&f, q) || vbm_launch_pack(&f, q)) return -2;
     }
     return vbm_launch_bitrate_choose(&v, d_packets, q);

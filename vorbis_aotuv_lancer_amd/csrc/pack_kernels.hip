@@ -311,6 +311,7 @@ __device__ __forceinline__ res_view residue_view(const vbm_batch &b, const vbm_m
 // this runs after it and before the residue kernels
 __global__ void k_nonzero_propagate(vbm_batch b)
 {
+    vbm_blob_enter(b);
     const int sb = blockIdx.x * blockDim.x + threadIdx.x;
     if (sb >= vbm_nsb(b)) return;
     const vbm_map *info = &b.setup->map[b.W];
@@ -327,6 +328,7 @@ __global__ void k_nonzero_propagate(vbm_batch b)
 // packet header and the floors' bits: needs floor1_encode's values only, so it may run beside couple/quantise
 __global__ void k_pack_head(vbm_batch b)
 {
+    vbm_blob_enter(b);
     const int sb = blockIdx.x * blockDim.x + threadIdx.x;
     if (sb >= vbm_nsb(b)) return;
     const size_t SW = b.slab_words;
@@ -663,6 +665,7 @@ __device__ __forceinline__ void res_classify(const vbm_batch &b, const res_view 
 
 __global__ void k_res_vq(vbm_batch b, int sm, int nchunks)
 {
+    vbm_blob_enter(b);
     extern __shared__ int vq_lds[];   // [samples per partition][64 lanes]
     const int sb = blockIdx.x * blockDim.x + threadIdx.x;
     if (sb >= vbm_nsb(b)) return;
@@ -733,6 +736,7 @@ __global__ void k_res_vq(vbm_batch b, int sm, int nchunks)
 
 __global__ void k_res_offsets(vbm_batch b, int sm)
 {
+    vbm_blob_enter(b);
     const int sb = blockIdx.x * blockDim.x + threadIdx.x;
     if (sb >= vbm_nsb(b)) return;
     const vbm_setup *s = b.setup;
@@ -822,6 +826,7 @@ __global__ void k_res_offsets(vbm_batch b, int sm)
 
 __global__ void k_res_emit(vbm_batch b, int sm, int nchunks)
 {
+    vbm_blob_enter(b);
     const int sb = blockIdx.x * blockDim.x + threadIdx.x;
     if (sb >= vbm_nsb(b)) return;
     const vbm_map *info = &b.setup->map[b.W];
@@ -1296,36 +1301,39 @@ extern "C" int vbm_launch_bitrate_choose(const vbm_batch *b, uint8_t *d_packets,
 
 // the packet tiles start out as zeros (the bit runs are OR-ed in); a kernel of our own rather than hipMemsetAsync, so
 // that the launch sequence of a round is kernels only (it is replayed as a HIP graph, capi_encoder.cpp)
-static __global__ void k_zero_u128(uint4 *__restrict__ p, size_t n)
+static __global__ void k_zero_u128(uint4 *__restrict__ p, size_t n, size_t blob_stride)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (i < n) p[(size_t)blockIdx.z * blob_stride + i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 extern "C" int vbm_launch_pack_head(const vbm_batch *b, hipStream_t st)
 {
     const unsigned tiles = (unsigned)((b->nsb + 63) / 64);
+    const unsigned nbl = (unsigned)(b->nblobs > 1 ? b->nblobs : 1);      // managed bitrate: a packetblob per blockIdx.z
     {
         const size_t n16 = (size_t)tiles * 64 * b->max_packet_bytes / 16;   // max_packet_bytes is a multiple of 4: 64 * 4 = 256 B per row group
-        hipLaunchKernelGGL(k_zero_u128, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, (uint4 *)b->packetT, n16);
+        hipLaunchKernelGGL(k_zero_u128, dim3((unsigned)((n16 + 255) / 256), 1, nbl), dim3(256), 0, st, (uint4 *)b->packetT, n16,
+                           (size_t)b->Ls * b->max_packet_bytes / 16);
     }
-    hipLaunchKernelGGL(k_pack_head, dim3(tiles), dim3(64), 0, st, *b);
+    hipLaunchKernelGGL(k_pack_head, dim3(tiles, 1, nbl), dim3(64), 0, st, *b);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 extern "C" int vbm_launch_pack_residue(const vbm_batch *b, hipStream_t st)
 {
     const unsigned tiles = (unsigned)((b->nsb + 63) / 64);
-    hipLaunchKernelGGL(k_nonzero_propagate, dim3(tiles), dim3(64), 0, st, *b);
+    const unsigned nbl = (unsigned)(b->nblobs > 1 ? b->nblobs : 1);
+    hipLaunchKernelGGL(k_nonzero_propagate, dim3(tiles, 1, nbl), dim3(64), 0, st, *b);
     for (int sm = 0; sm < b->pack_submaps; sm++) {
         // (a small batch is bound by the length of a slice's walk: one partition per slice there)
         const int most = (b->few || b->nsb <= 1024) ? 256 : 32;
         int nchunks = b->pack_partvals[sm] < most ? b->pack_partvals[sm] : most;
         if (nchunks < 1) nchunks = 1;
-        hipLaunchKernelGGL(k_res_vq, dim3(tiles, (unsigned)nchunks), dim3(64), (size_t)b->pack_spp[sm] * 64 * sizeof(int), st, *b,
+        hipLaunchKernelGGL(k_res_vq, dim3(tiles, (unsigned)nchunks, nbl), dim3(64), (size_t)b->pack_spp[sm] * 64 * sizeof(int), st, *b,
                            sm, nchunks);
-        hipLaunchKernelGGL(k_res_offsets, dim3(tiles), dim3(64), 0, st, *b, sm);
-        hipLaunchKernelGGL(k_res_emit, dim3(tiles, (unsigned)nchunks), dim3(64), 0, st, *b, sm, nchunks);
+        hipLaunchKernelGGL(k_res_offsets, dim3(tiles, 1, nbl), dim3(64), 0, st, *b, sm);
+        hipLaunchKernelGGL(k_res_emit, dim3(tiles, (unsigned)nchunks, nbl), dim3(64), 0, st, *b, sm, nchunks);
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

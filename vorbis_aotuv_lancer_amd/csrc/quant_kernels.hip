@@ -229,6 +229,7 @@ __device__ __forceinline__ float noise_normalize(const nn_consts *p, const int l
 // M6 statistics of one partition, lib/psy.c:5010-5034 (the part that does not depend on side_resdef)
 __global__ void k_couple_m6stats(vbm_batch b)
 {
+    vbm_blob_enter(b);
     const int sb = blockIdx.x * blockDim.x + threadIdx.x;
     if (sb >= vbm_nsb(b)) return;
     const size_t SW = b.slab_words;
@@ -698,19 +699,10 @@ __global__ __launch_bounds__(FP * FPC) void k_couple_fast(vbm_batch b)
     const vbm_setup *s = b.setup;
     const vbm_psy *p = &s->psy[b.block_mode];
     const vbm_map *vi = &s->map[b.W];
-    const int blobno = b.blobno;
     const size_t SW = b.slab_words;
     const int NCH = (MODE == 1) ? 2 : 1;
     fast_consts c;
     c.n = p->n;
-    c.limit = s->coupling_pointlimit[p->blockflag][blobno];
-    c.prepoint = (float)s->stereo_threshholds[s->coupling_prepointamp[blobno]];
-    c.postpoint = (float)s->stereo_threshholds[s->coupling_postpointamp[blobno]];
-    c.prepoint_x = (float)s->stereo_threshholds_X[s->coupling_prepointamp[blobno]];
-    c.postpoint_x = (float)s->stereo_threshholds_X[s->coupling_postpointamp[blobno]];
-    if (c.prepoint_x < c.prepoint) c.prepoint_x = c.prepoint;
-    if (c.postpoint_x < c.prepoint) c.postpoint_x = c.prepoint;
-    c.sliding_lowpass = s->sliding_lowpass[b.W][blobno];
     c.tonefix_end = p->tonefix_end;
     c.prae = (vi->coupling_steps == 1) ? (float)0.34 : (float)0.825;
     c.nn.normal_p = p->normal_p; c.nn.normal_start = p->normal_start; c.nn.normal_thresh = p->normal_thresh;
@@ -735,27 +727,59 @@ __global__ __launch_bounds__(FP * FPC) void k_couple_fast(vbm_batch b)
             const size_t a = (cb >> 6) * SW + (size_t)(i + lr) * 64 + (cb & 63);
             L.in_md[k][lr][lc] = b.mdctT[a];
             L.in_ep[k][lr][lc] = b.epeakT[a];
-            L.in_iw[k][lr][lc] = b.iworkT[a];
+        }
+    }
+
+    // compute lanes: (column g, bin j)
+    const int g = tid >> 5, j = tid & 31;
+    const int col = blockIdx.x * FPC + g;
+    const int lane = tid & 63, base = lane & 32;
+    const int jn = FP > c.n - i ? c.n - i : FP;
+    // noise peaks of the partition: read once; a managed block's packetblobs hand them on to one another
+    // (_vp_couple_quantize_normalize rewrites NP(Mi) where it point-couples, lib/psy.c:5100-5108, and the reference's
+    // loop over the blobs passes the same rows every time, lib/mapping0.c:1249-1260)
+    float npk[2] = {0.f, 0.f};
+    if (!past && col < ncols)
+#pragma unroll
+        for (int k = 0; k < NCH; k++) {
+            const size_t cb = (MODE == 1) ? (size_t)col * 2 + k : (size_t)col;
+            npk[k] = b.npeakT[(cb >> 6) * SW + (size_t)pi * 64 + (cb & 63)];
+        }
+
+    const int nbl = b.nblobs > 1 ? b.nblobs : 1;
+    for (int kb = 0; kb < nbl; kb++) {
+    if (nbl > 1) {
+        __syncthreads();                 // (the store of the blob before this one is done with in_iw)
+        vbm_blob_select(b, kb);
+    }
+    const int blobno = b.blobno;
+    c.limit = s->coupling_pointlimit[p->blockflag][blobno];
+    c.prepoint = (float)s->stereo_threshholds[s->coupling_prepointamp[blobno]];
+    c.postpoint = (float)s->stereo_threshholds[s->coupling_postpointamp[blobno]];
+    c.prepoint_x = (float)s->stereo_threshholds_X[s->coupling_prepointamp[blobno]];
+    c.postpoint_x = (float)s->stereo_threshholds_X[s->coupling_postpointamp[blobno]];
+    if (c.prepoint_x < c.prepoint) c.prepoint_x = c.prepoint;
+    if (c.postpoint_x < c.prepoint) c.postpoint_x = c.prepoint;
+    c.sliding_lowpass = s->sliding_lowpass[b.W][blobno];
+    if (!past && colL < ncols && i + lr < c.n) {
+#pragma unroll
+        for (int k = 0; k < NCH; k++) {
+            const size_t cb = (MODE == 1) ? (size_t)colL * 2 + k : (size_t)colL;
+            L.in_iw[k][lr][lc] = b.iworkT[(cb >> 6) * SW + (size_t)(i + lr) * 64 + (cb & 63)];
         }
     }
     __syncthreads();
 
     // ---- compute: lane = (column g, bin j) ---------------------------------------------------
-    const int g = tid >> 5, j = tid & 31;
-    const int col = blockIdx.x * FPC + g;
-    const int lane = tid & 63, base = lane & 32;
-    const int jn = FP > c.n - i ? c.n - i : FP;
     int out[2] = {0, 0};
     if (!past && col < ncols) {
         float raw[2], quant[2], floor[2], res[2];
         int flag[2];
         bool nz[2];
-        float npk[2];
 #pragma unroll
         for (int k = 0; k < NCH; k++) {
             const size_t cb = (MODE == 1) ? (size_t)col * 2 + k : (size_t)col;
             nz[k] = b.nonzero[cb] != 0;
-            npk[k] = b.npeakT[(cb >> 6) * SW + (size_t)pi * 64 + (cb & 63)];
             fast_channel(c, L, fromdB, g, j, i, jn, nz[k], L.in_md[k][j][g], L.in_ep[k][j][g], L.in_iw[k][j][g], npk[k],
                          raw[k], quant[k], floor[k], res[k], flag[k], out[k]);
         }
@@ -824,6 +848,7 @@ __global__ __launch_bounds__(FP * FPC) void k_couple_fast(vbm_batch b)
                     // NP(Mi) = -1 or min(NP(Mi), NP(Ai)) — idempotent, the source repeats it per lossy bin
                     if (((double)npM < -0.5) || ((double)npA < -0.5)) npM = -1;
                     else npM = VMIN(npM, npA);
+                    npk[Mi & 1] = npM;       // (every lane of the half-wave holds it: the next packetblob starts from here)
                     if (j == 0) {
                         const size_t cbM = (size_t)col * 2 + Mi;
                         b.npeakT[(cbM >> 6) * SW + (size_t)pi * 64 + (cbM & 63)] = npM;
@@ -856,7 +881,7 @@ __global__ __launch_bounds__(FP * FPC) void k_couple_fast(vbm_batch b)
     //      channels, res_bm[column][bin * NCH + channel] (lib/res0.c:781-787) — straight from the lane that holds it: the 32
     //      lanes of a half-wave write 32 * NCH consecutive ints.  Otherwise: tiled rows, back through LDS so that they go out
     //      coalesced.
-    if (b.pack_fused) {
+    if (b.pack_fused) {      // (never a managed setup: one pass)
         if (col < ncols && i + j < c.n) {
             if (MODE == 1) {
                 int2 *dst = reinterpret_cast<int2 *>(b.res_bm + (size_t)col * c.n * 2) + (i + j);
@@ -879,6 +904,7 @@ __global__ __launch_bounds__(FP * FPC) void k_couple_fast(vbm_batch b)
             b.iworkT[(cb >> 6) * SW + (size_t)(i + lr) * 64 + (cb & 63)] = L.in_iw[k][lr][lc];
         }
     }
+    }   // packetblobs
 }
 
 }  // namespace
@@ -894,7 +920,8 @@ extern "C" int vbm_launch_couple_quantize(const vbm_batch *b, hipStream_t st)
     }
     if (b->couple_fast == 2) {
         if (b->couple_m6parts > 0)
-            hipLaunchKernelGGL(k_couple_m6stats, dim3(tiles, (unsigned)b->couple_m6parts), dim3(64), 0, st, *b);
+            hipLaunchKernelGGL(k_couple_m6stats, dim3(tiles, (unsigned)b->couple_m6parts, (unsigned)(b->nblobs > 1 ? b->nblobs : 1)),
+                               dim3(64), 0, st, *b);
         hipLaunchKernelGGL(k_couple_fast<1>, dim3((unsigned)((b->nsb + FPC - 1) / FPC), (unsigned)(b->n / FP)), dim3(FP * FPC), 0,
                            st, *b);
         return hipGetLastError() == hipSuccess ? 0 : -2;
@@ -902,7 +929,8 @@ extern "C" int vbm_launch_couple_quantize(const vbm_batch *b, hipStream_t st)
     int nchunks = 1;
     if (b->couple_parallel) {
         if (b->couple_m6parts > 0)
-            hipLaunchKernelGGL(k_couple_m6stats, dim3(tiles, (unsigned)b->couple_m6parts), dim3(64), 0, st, *b);
+            hipLaunchKernelGGL(k_couple_m6stats, dim3(tiles, (unsigned)b->couple_m6parts, (unsigned)(b->nblobs > 1 ? b->nblobs : 1)),
+                               dim3(64), 0, st, *b);
         nchunks = b->couple_parts < 32 ? (b->couple_parts > 0 ? b->couple_parts : 1) : 32;
     }
     hipLaunchKernelGGL(k_couple_quantize, dim3(tiles, (unsigned)nchunks), dim3(64), 0, st, *b, nchunks);
