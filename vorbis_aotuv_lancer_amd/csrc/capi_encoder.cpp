@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <functional>
 #include <string>
 #include <algorithm>
 #include <thread>
@@ -625,7 +626,9 @@ static int managed_front(const vbm_batch &v, hipStream_t q)
 
 // loop C once per packetblob (lib/mapping0.c:1204-1313), then vorbis_bitrate_addblock / _flushpacket
 // (lib/bitrate.c:98-252): choice, final lengths, the chosen packets
-static int managed_back(const vbm_batch &v, uint8_t *d_packets, hipStream_t q)
+// `before_choose`: called between the blobs' passes and the bitrate manager's choice (the only step of the back half that
+// touches state carried from block to block: bm_avg_reservoir / bm_minmax_reservoir / bm_avgfloat of the streams)
+static int managed_back(const vbm_batch &v, uint8_t *d_packets, hipStream_t q, const std::function<int()> &before_choose = nullptr)
 {
     static const int wide = getenv("VBM_MANAGED_WIDE") ? atoi(getenv("VBM_MANAGED_WIDE")) : 1;
     if (wide) {
@@ -646,6 +649,7 @@ static int managed_back(const vbm_batch &v, uint8_t *d_packets, hipStream_t q)
             }
         }
         if (vbm_launch_pack(&f, q)) return -2;
+        if (before_choose && before_choose()) return -2;
         return vbm_launch_bitrate_choose(&v, d_packets, q);
     }
     for (int k = 0; k < VBM_PACKETBLOBS; k++) {
@@ -653,6 +657,7 @@ static int managed_back(const vbm_batch &v, uint8_t *d_packets, hipStream_t q)
         vbm_blob_select(f, k);
         if (vbm_launch_floor_encode(&f, q) || vbm_launch_couple_quantize(&f, q) || vbm_launch_pack(&f, q)) return -2;
     }
+    if (before_choose && before_choose()) return -2;
     return vbm_launch_bitrate_choose(&v, d_packets, q);
 }
 
@@ -923,8 +928,8 @@ static int enqueue_job(vbm_encoder *e, const type_job &j)
     if (!j.grouped)
     for (int ww = 0; ww < e->nws; ww++)
         for (int t = 0; t < 4; t++)
-            if (((j.depmask >> (ww * 4 + t)) & 1u) && (e->slot_queue[ww][t] != qid || s->managed) &&
-                (err = hipStreamWaitEvent(q, s->managed ? e->ev_done[ww][t] : e->ev_state[ww][t], 0)) != hipSuccess)
+            if (((j.depmask >> (ww * 4 + t)) & 1u) && e->slot_queue[ww][t] != qid &&
+                (err = hipStreamWaitEvent(q, e->ev_state[ww][t], 0)) != hipSuccess)
                 return vbm_set_hip_error(err, "hipStreamWaitEvent");
     if (!j.grouped) vbm_debug_delay_point(VBM_DP_JOB_STATE, q);
     { TIMED(3, q); RUN(vbm_launch_prologue(&v, q)); }
@@ -946,7 +951,16 @@ static int enqueue_job(vbm_encoder *e, const type_job &j)
     }
     if (s->managed) {
         TIMED(10, q);
-        RUN(managed_back(v, j.d_packets, q));
+        // a managed stream's reservoirs move in the bitrate manager's choice at the end of the back half: that step (not
+        // the front half, not the blobs' passes) waits for the DONE events of the batches this one's streams were in
+        hipStream_t qb = q;
+        RUN(managed_back(v, j.d_packets, q, [&]() -> int {
+            if (j.grouped) return 0;
+            for (int ww = 0; ww < e->nws; ww++)
+                for (int t = 0; t < 4; t++)
+                    if (((j.depmask >> (ww * 4 + t)) & 1u) && hipStreamWaitEvent(qb, e->ev_done[ww][t], 0) != hipSuccess) return -2;
+            return 0;
+        }));
     } else {
         { TIMED(7, q); RUN(vbm_launch_floor_fit(&v, q)); }
         { TIMED(8, q); RUN(vbm_launch_floor_encode(&v, q)); }
