@@ -51,10 +51,17 @@ def signals(nchunks, period):
     return _cache[key]
 
 
-def oracle_want(oracle, nchunks, period):
-    key = ("want", nchunks, period)
+MANAGED = (144000, 128000, 112000)     # vorbis_encode_init(max, nominal, min): the bitrate manager's reservoirs are carried state
+
+
+def make_setup(v, bitrate):
+    return v.Setup(CH, RATE, bitrate=bitrate) if bitrate else v.Setup(CH, RATE, Q)
+
+
+def oracle_want(oracle, nchunks, period, bitrate=None):
+    key = ("want", nchunks, period, bitrate)
     if key not in _cache:
-        osetup = orc.Setup(oracle, CH, RATE, Q)
+        osetup = orc.Setup(oracle, CH, RATE, None if bitrate else Q, bitrate=bitrate)
         want = []
         for sig in signals(nchunks, period):
             st = orc.Stream(osetup)
@@ -79,10 +86,10 @@ def drain_host(fe, led, label):
         led.add_host_round(info, packets, nbytes, label)
 
 
-def run_host_rounds(cuda, nchunks, period, poison=False, multi=False):
+def run_host_rounds(cuda, nchunks, period, poison=False, multi=False, bitrate=None):
     import vorbis_aotuv_lancer_amd as v
     base = torch.from_numpy(np.stack(signals(nchunks, period))).to(cuda)
-    enc = v.Encoder(v.Setup(CH, RATE, Q), S)
+    enc = v.Encoder(make_setup(v, bitrate), S)
     fe = v.FrontEnd(enc)
     led = TwinLedger(S, K, cuda)
     for c in range(nchunks):
@@ -106,11 +113,11 @@ def run_host_rounds(cuda, nchunks, period, poison=False, multi=False):
     return led
 
 
-def run_device_rounds(cuda, monkeypatch, nchunks, period, poison=False, lazy=2):
+def run_device_rounds(cuda, monkeypatch, nchunks, period, poison=False, lazy=2, bitrate=None):
     import vorbis_aotuv_lancer_amd as v
     monkeypatch.setenv("VBM_WORKSPACES", "4")
     base = torch.from_numpy(np.stack(signals(nchunks, period))).to(cuda)
-    setup = v.Setup(CH, RATE, Q)
+    setup = make_setup(v, bitrate)
     enc = v.Encoder(setup, S, max_batch=v.lib.vbm_device_round_lanes(setup._h, S))
     fe = v.FrontEnd(enc)
     led = TwinLedger(S, K, cuda)
@@ -138,8 +145,8 @@ def run_device_rounds(cuda, monkeypatch, nchunks, period, poison=False, lazy=2):
     return led
 
 
-def check_oracle(led, oracle, nchunks, period):
-    want = oracle_want(oracle, nchunks, period)
+def check_oracle(led, oracle, nchunks, period, bitrate=None):
+    want = oracle_want(oracle, nchunks, period, bitrate)
     for k in range(K):
         assert led.lead_packets(k) == want[k], f"signal {k}: packets differ from the oracle"
     assert led.modes[0] + led.modes[1] > 0 and led.modes[2] > 0 and led.modes[3] > 0, led.modes   # all block types ran
@@ -168,6 +175,28 @@ def test_device_built_rounds_with_delays(oracle, cuda, monkeypatch, delay, point
     if point != "none":
         delay(point)
     check_oracle(run_device_rounds(cuda, monkeypatch, nchunks, period), oracle, nchunks, period)
+
+
+@pytest.mark.parametrize("point", ["none", "job_back", "job_small", "job_out", "job_state"])
+def test_managed_host_built_rounds_with_delays(oracle, cuda, delay, point):
+    """Managed bitrate: the front half and the fifteen packetblobs of a batch run beside the back halves of the batches
+    before it; the bitrate manager's choice (reservoirs: state carried from block to block, lib/bitrate.c:98-226) is the
+    step that waits for them.  A stream changes block type — and with it the internal HIP stream — at every burst; with
+    the back half of a batch held up, a choice that did not wait would see reservoirs one block old.  (Tried and not kept: a
+    case that switches the wait off and expects different packets — the reservoirs' sums do not depend on the order of the
+    additions, so a mis-ordered choice only shows when it flips a choice, which a third of a second of audio does not do.)"""
+    nchunks, period = 10, 6000
+    if point != "none":
+        delay(point)
+    check_oracle(run_host_rounds(cuda, nchunks, period, bitrate=MANAGED), oracle, nchunks, period, MANAGED)
+
+
+@pytest.mark.parametrize("point", ["none", "job_back", "job_big", "job_out"])
+def test_managed_device_built_rounds_with_delays(oracle, cuda, monkeypatch, delay, point):
+    nchunks, period = 12, 6000
+    if point != "none":
+        delay(point)
+    check_oracle(run_device_rounds(cuda, monkeypatch, nchunks, period, bitrate=MANAGED), oracle, nchunks, period, MANAGED)
 
 
 def test_host_built_rounds_poisoned_scratch(oracle, cuda):
