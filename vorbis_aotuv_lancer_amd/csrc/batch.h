@@ -142,10 +142,14 @@ void vbm_blob_select(vbm_batch &b, int k)
 }
 
 #ifdef __HIPCC__
-// first statement of a back-half kernel that runs a blob per blockIdx.z
+// First statement of a back-half kernel.  The kernels are templates on BLOBS: the managed instantiation takes the blob from
+// blockIdx.z; the other one leaves its argument alone (a kernel argument that is written to moves, with the arrays that
+// are indexed at run time, from the constant kernarg segment into registers and scratch: measured on k_res_vq and the
+// couple kernel, + 17 % on the from-PCM step).
+template <bool BLOBS>
 __device__ __forceinline__ void vbm_blob_enter(vbm_batch &b)
 {
-    if (b.nblobs > 1) vbm_blob_select(b, (int)blockIdx.z);
+    if (BLOBS) vbm_blob_select(b, (int)blockIdx.z);
 }
 __device__ __forceinline__ int vbm_nsb(const vbm_batch &b) { return b.d_nsb ? *b.d_nsb : b.nsb; }
 __device__ __forceinline__ int vbm_ncb(const vbm_batch &b) { return vbm_nsb(b) * b.ch; }

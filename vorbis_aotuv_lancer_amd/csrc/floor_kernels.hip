@@ -883,9 +883,10 @@ __global__ void k_floor_interp(vbm_batch b)
     }
 }
 
+template <bool BLOBS>
 __global__ void k_floor_encode(vbm_batch b)
 {
-    vbm_blob_enter(b);
+    vbm_blob_enter<BLOBS>(b);
     const int lane = blockIdx.x * blockDim.x + threadIdx.x;
     if (lane >= vbm_ncb(b)) return;
     const size_t tb = (size_t)(lane >> 6) * b.slab_words + (lane & 63);
@@ -957,9 +958,10 @@ __global__ void k_floor_encode(vbm_batch b)
 // sliced over the bins: slice blockIdx.y draws bins [r0, r1) of every channel-block.  A line that starts
 // before the slice is entered at x = r0 with the state its Bresenham walk has there: after k steps the
 // walk has taken floor(k * ady / adx) of the long steps and carries err = (k * ady) mod adx.
+template <bool BLOBS>
 __global__ void k_floor_render(vbm_batch b, int nchunks)
 {
-    vbm_blob_enter(b);
+    vbm_blob_enter<BLOBS>(b);
     const int lane = blockIdx.x * blockDim.x + threadIdx.x;
     if (lane >= vbm_ncb(b)) return;
     const size_t tb = (size_t)(lane >> 6) * b.slab_words + (lane & 63);
@@ -1074,9 +1076,13 @@ extern "C" int vbm_launch_floor_interp(const vbm_batch *b, hipStream_t st)
 extern "C" int vbm_launch_floor_encode(const vbm_batch *b, hipStream_t st)
 {
     const unsigned nbl = (unsigned)(b->nblobs > 1 ? b->nblobs : 1);      // managed bitrate: a packetblob per blockIdx.z
-    hipLaunchKernelGGL(k_floor_encode, dim3((unsigned)((b->ncb + 63) / 64), 1, nbl), dim3(64), 0, st, *b);
+    if (nbl > 1) hipLaunchKernelGGL(k_floor_encode<true>, dim3((unsigned)((b->ncb + 63) / 64), 1, nbl), dim3(64), 0, st, *b);
+    else hipLaunchKernelGGL(k_floor_encode<false>, dim3((unsigned)((b->ncb + 63) / 64)), dim3(64), 0, st, *b);
     int nchunks = b->n >= 1024 ? 8 : b->n >= 256 ? 4 : 2;
     if ((b->few || b->ncb <= 1024) && b->n / 16 > nchunks) nchunks = b->n / 16;   // small batch: latency-bound, finer slices
-    hipLaunchKernelGGL(k_floor_render, dim3((unsigned)((b->ncb + 63) / 64), (unsigned)nchunks, nbl), dim3(64), 0, st, *b, nchunks);
+    if (nbl > 1)
+        hipLaunchKernelGGL(k_floor_render<true>, dim3((unsigned)((b->ncb + 63) / 64), (unsigned)nchunks, nbl), dim3(64), 0, st, *b, nchunks);
+    else
+        hipLaunchKernelGGL(k_floor_render<false>, dim3((unsigned)((b->ncb + 63) / 64), (unsigned)nchunks), dim3(64), 0, st, *b, nchunks);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -309,9 +309,10 @@ __device__ __forceinline__ res_view residue_view(const vbm_batch &b, const vbm_m
 
 // nonzero[] after coupling (lib/psy.c:5133-5140); couple/quantise reads the flags as floor1_encode left them, so
 // this runs after it and before the residue kernels
+template <bool BLOBS>
 __global__ void k_nonzero_propagate(vbm_batch b)
 {
-    vbm_blob_enter(b);
+    vbm_blob_enter<BLOBS>(b);
     const int sb = blockIdx.x * blockDim.x + threadIdx.x;
     if (sb >= vbm_nsb(b)) return;
     const vbm_map *info = &b.setup->map[b.W];
@@ -326,9 +327,10 @@ __global__ void k_nonzero_propagate(vbm_batch b)
 }
 
 // packet header and the floors' bits: needs floor1_encode's values only, so it may run beside couple/quantise
+template <bool BLOBS>
 __global__ void k_pack_head(vbm_batch b)
 {
-    vbm_blob_enter(b);
+    vbm_blob_enter<BLOBS>(b);
     const int sb = blockIdx.x * blockDim.x + threadIdx.x;
     if (sb >= vbm_nsb(b)) return;
     const size_t SW = b.slab_words;
@@ -663,9 +665,10 @@ __device__ __forceinline__ void res_classify(const vbm_batch &b, const res_view 
     }
 }
 
+template <bool BLOBS>
 __global__ void k_res_vq(vbm_batch b, int sm, int nchunks)
 {
-    vbm_blob_enter(b);
+    vbm_blob_enter<BLOBS>(b);
     extern __shared__ int vq_lds[];   // [samples per partition][64 lanes]
     const int sb = blockIdx.x * blockDim.x + threadIdx.x;
     if (sb >= vbm_nsb(b)) return;
@@ -734,9 +737,10 @@ __global__ void k_res_vq(vbm_batch b, int sm, int nchunks)
     }
 }
 
+template <bool BLOBS>
 __global__ void k_res_offsets(vbm_batch b, int sm)
 {
-    vbm_blob_enter(b);
+    vbm_blob_enter<BLOBS>(b);
     const int sb = blockIdx.x * blockDim.x + threadIdx.x;
     if (sb >= vbm_nsb(b)) return;
     const vbm_setup *s = b.setup;
@@ -824,9 +828,10 @@ __global__ void k_res_offsets(vbm_batch b, int sm)
     b.packet_bytes[sb] = (pos > maxwords * 32) ? -1 : (pos + 7) / 8;
 }
 
+template <bool BLOBS>
 __global__ void k_res_emit(vbm_batch b, int sm, int nchunks)
 {
-    vbm_blob_enter(b);
+    vbm_blob_enter<BLOBS>(b);
     const int sb = blockIdx.x * blockDim.x + threadIdx.x;
     if (sb >= vbm_nsb(b)) return;
     const vbm_map *info = &b.setup->map[b.W];
@@ -1316,7 +1321,8 @@ extern "C" int vbm_launch_pack_head(const vbm_batch *b, hipStream_t st)
         hipLaunchKernelGGL(k_zero_u128, dim3((unsigned)((n16 + 255) / 256), 1, nbl), dim3(256), 0, st, (uint4 *)b->packetT, n16,
                            (size_t)b->Ls * b->max_packet_bytes / 16);
     }
-    hipLaunchKernelGGL(k_pack_head, dim3(tiles, 1, nbl), dim3(64), 0, st, *b);
+    if (nbl > 1) hipLaunchKernelGGL(k_pack_head<true>, dim3(tiles, 1, nbl), dim3(64), 0, st, *b);
+    else hipLaunchKernelGGL(k_pack_head<false>, dim3(tiles), dim3(64), 0, st, *b);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -1324,16 +1330,23 @@ extern "C" int vbm_launch_pack_residue(const vbm_batch *b, hipStream_t st)
 {
     const unsigned tiles = (unsigned)((b->nsb + 63) / 64);
     const unsigned nbl = (unsigned)(b->nblobs > 1 ? b->nblobs : 1);
-    hipLaunchKernelGGL(k_nonzero_propagate, dim3(tiles, 1, nbl), dim3(64), 0, st, *b);
+    if (nbl > 1) hipLaunchKernelGGL(k_nonzero_propagate<true>, dim3(tiles, 1, nbl), dim3(64), 0, st, *b);
+    else hipLaunchKernelGGL(k_nonzero_propagate<false>, dim3(tiles), dim3(64), 0, st, *b);
     for (int sm = 0; sm < b->pack_submaps; sm++) {
         // (a small batch is bound by the length of a slice's walk: one partition per slice there)
         const int most = (b->few || b->nsb <= 1024) ? 256 : 32;
         int nchunks = b->pack_partvals[sm] < most ? b->pack_partvals[sm] : most;
         if (nchunks < 1) nchunks = 1;
-        hipLaunchKernelGGL(k_res_vq, dim3(tiles, (unsigned)nchunks, nbl), dim3(64), (size_t)b->pack_spp[sm] * 64 * sizeof(int), st, *b,
-                           sm, nchunks);
-        hipLaunchKernelGGL(k_res_offsets, dim3(tiles, 1, nbl), dim3(64), 0, st, *b, sm);
-        hipLaunchKernelGGL(k_res_emit, dim3(tiles, (unsigned)nchunks, nbl), dim3(64), 0, st, *b, sm, nchunks);
+        const size_t lds = (size_t)b->pack_spp[sm] * 64 * sizeof(int);
+        if (nbl > 1) {
+            hipLaunchKernelGGL(k_res_vq<true>, dim3(tiles, (unsigned)nchunks, nbl), dim3(64), lds, st, *b, sm, nchunks);
+            hipLaunchKernelGGL(k_res_offsets<true>, dim3(tiles, 1, nbl), dim3(64), 0, st, *b, sm);
+            hipLaunchKernelGGL(k_res_emit<true>, dim3(tiles, (unsigned)nchunks, nbl), dim3(64), 0, st, *b, sm, nchunks);
+        } else {
+            hipLaunchKernelGGL(k_res_vq<false>, dim3(tiles, (unsigned)nchunks), dim3(64), lds, st, *b, sm, nchunks);
+            hipLaunchKernelGGL(k_res_offsets<false>, dim3(tiles), dim3(64), 0, st, *b, sm);
+            hipLaunchKernelGGL(k_res_emit<false>, dim3(tiles, (unsigned)nchunks), dim3(64), 0, st, *b, sm, nchunks);
+        }
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

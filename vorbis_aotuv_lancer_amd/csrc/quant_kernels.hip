@@ -227,9 +227,10 @@ __device__ __forceinline__ float noise_normalize(const nn_consts *p, const int l
 }
 
 // M6 statistics of one partition, lib/psy.c:5010-5034 (the part that does not depend on side_resdef)
+template <bool BLOBS>
 __global__ void k_couple_m6stats(vbm_batch b)
 {
-    vbm_blob_enter(b);
+    vbm_blob_enter<BLOBS>(b);
     const int sb = blockIdx.x * blockDim.x + threadIdx.x;
     if (sb >= vbm_nsb(b)) return;
     const size_t SW = b.slab_words;
@@ -691,9 +692,10 @@ __device__ __forceinline__ void fast_channel(const fast_consts &c, fast_lds &L, 
     }
 }
 
-template <int MODE>
-__global__ __launch_bounds__(FP * FPC) void k_couple_fast(vbm_batch b)
+template <int MODE, bool BLOBS>
+__global__ __launch_bounds__(FP * FPC) void k_couple_fast(vbm_batch b_in)
 {
+    vbm_batch b = b_in;
     __shared__ fast_lds L;
     if ((int)(blockIdx.x * FPC) >= ((MODE == 1) ? vbm_nsb(b) : vbm_ncb(b))) return;   // (launch bound > device-resident count)
     const vbm_setup *s = b.setup;
@@ -746,9 +748,9 @@ __global__ __launch_bounds__(FP * FPC) void k_couple_fast(vbm_batch b)
             npk[k] = b.npeakT[(cb >> 6) * SW + (size_t)pi * 64 + (cb & 63)];
         }
 
-    const int nbl = b.nblobs > 1 ? b.nblobs : 1;
+    const int nbl = BLOBS ? b.nblobs : 1;
     for (int kb = 0; kb < nbl; kb++) {
-    if (nbl > 1) {
+    if (BLOBS) {
         __syncthreads();                 // (the store of the blob before this one is done with in_iw)
         vbm_blob_select(b, kb);
     }
@@ -914,23 +916,32 @@ extern "C" int vbm_launch_couple_quantize(const vbm_batch *b, hipStream_t st)
     const unsigned tiles = (unsigned)((b->nsb + 63) / 64);
     // fast path: 32-bin partitions with no coupling, or stereo with one coupling step
     if (b->couple_fast == 1) {
-        hipLaunchKernelGGL(k_couple_fast<0>, dim3((unsigned)((b->ncb + FPC - 1) / FPC), (unsigned)(b->n / FP)), dim3(FP * FPC), 0,
-                           st, *b);
+        if (b->nblobs > 1)
+            hipLaunchKernelGGL((k_couple_fast<0, true>), dim3((unsigned)((b->ncb + FPC - 1) / FPC), (unsigned)(b->n / FP)), dim3(FP * FPC), 0,
+                               st, *b);
+        else
+            hipLaunchKernelGGL((k_couple_fast<0, false>), dim3((unsigned)((b->ncb + FPC - 1) / FPC), (unsigned)(b->n / FP)), dim3(FP * FPC), 0,
+                               st, *b);
         return hipGetLastError() == hipSuccess ? 0 : -2;
     }
     if (b->couple_fast == 2) {
-        if (b->couple_m6parts > 0)
-            hipLaunchKernelGGL(k_couple_m6stats, dim3(tiles, (unsigned)b->couple_m6parts, (unsigned)(b->nblobs > 1 ? b->nblobs : 1)),
-                               dim3(64), 0, st, *b);
-        hipLaunchKernelGGL(k_couple_fast<1>, dim3((unsigned)((b->nsb + FPC - 1) / FPC), (unsigned)(b->n / FP)), dim3(FP * FPC), 0,
-                           st, *b);
+        if (b->nblobs > 1) {
+            if (b->couple_m6parts > 0)
+                hipLaunchKernelGGL(k_couple_m6stats<true>, dim3(tiles, (unsigned)b->couple_m6parts, (unsigned)b->nblobs), dim3(64), 0, st, *b);
+            hipLaunchKernelGGL((k_couple_fast<1, true>), dim3((unsigned)((b->nsb + FPC - 1) / FPC), (unsigned)(b->n / FP)), dim3(FP * FPC),
+                               0, st, *b);
+        } else {
+            if (b->couple_m6parts > 0)
+                hipLaunchKernelGGL(k_couple_m6stats<false>, dim3(tiles, (unsigned)b->couple_m6parts), dim3(64), 0, st, *b);
+            hipLaunchKernelGGL((k_couple_fast<1, false>), dim3((unsigned)((b->nsb + FPC - 1) / FPC), (unsigned)(b->n / FP)), dim3(FP * FPC),
+                               0, st, *b);
+        }
         return hipGetLastError() == hipSuccess ? 0 : -2;
     }
     int nchunks = 1;
     if (b->couple_parallel) {
         if (b->couple_m6parts > 0)
-            hipLaunchKernelGGL(k_couple_m6stats, dim3(tiles, (unsigned)b->couple_m6parts, (unsigned)(b->nblobs > 1 ? b->nblobs : 1)),
-                               dim3(64), 0, st, *b);
+            hipLaunchKernelGGL(k_couple_m6stats<false>, dim3(tiles, (unsigned)b->couple_m6parts), dim3(64), 0, st, *b);   // (general kernel: the host walks the blobs)
         nchunks = b->couple_parts < 32 ? (b->couple_parts > 0 ? b->couple_parts : 1) : 32;
     }
     hipLaunchKernelGGL(k_couple_quantize, dim3(tiles, (unsigned)nchunks), dim3(64), 0, st, *b, nchunks);
