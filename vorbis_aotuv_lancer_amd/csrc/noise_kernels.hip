@@ -763,10 +763,9 @@ extern "C" int vbm_launch_noisemask(const vbm_batch *b, hipStream_t st)
     if (n <= 256) return launch<8, 1>(b, st);
     if (n <= 512) return launch<4, 2>(b, st);
     if (n == 1024 && b->noise_ring) return launch<2, 4, true>(b, st);     // ring form: host-checked window reaches (configure())
-    {
-        static const int nb1 = getenv("VBM_NOISE_NB1") ? atoi(getenv("VBM_NOISE_NB1")) : 0;    // occupancy experiment
-        if (n == 1024 && nb1) return launch<1, 4>(b, st);
-    }
+    // (occupancy experiments, round 3, tools/gpu_noise_occ.sh / gpu_ab_env.sh: one block per workgroup — seven workgroups per
+    //  CU, 4-byte row stores — 0.90 ms alone; at most two workgroups per CU 0.96 ms alone and the from-PCM step 5.2 ms
+    //  against 4.7; four, see above.  Three it is.)
     if (n <= 1024) return launch<2, 4>(b, st);
     return launch<1, 16>(b, st);
 }

@@ -364,7 +364,8 @@ extern "C" int vbm_launch_tonemask(const vbm_batch *b, int tn, hipStream_t st)
     static const int phases = getenv("VBM_TONE_PHASES") ? atoi(getenv("VBM_TONE_PHASES")) : 31;
     // 8 blocks per workgroup (256 threads, ~38 KB of LDS).  Measured on MI355X, 16384 stereo streams: alone the kernel
     // takes the same 0.7 ms with 8, 16 or 32 blocks per workgroup, but beside the noise-mask branch and the previous
-    // step's back half (MDCT, couple and residue-VQ workgroups want LDS too) the step takes 3.07 / 3.19 / 3.22 ms.
+    // step's back half (MDCT, couple and residue-VQ workgroups want LDS too) the step takes 3.07 / 3.19 / 3.22 ms
+    // (round 3, four blocks per workgroup: per-block step 2.93 against 2.91, from PCM 4.83-5.02 against 4.67-4.71).
     static const int force = getenv("VBM_TONE_NB") ? atoi(getenv("VBM_TONE_NB")) : 8;
     if (force == 16) return launch<16>(b, tn, lds_bytes(16, tn), phases, st);
     return launch<8>(b, tn, lds_bytes(8, tn), phases, st);
