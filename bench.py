@@ -403,9 +403,11 @@ def main():
         t0 = time.perf_counter()
         for k in range(args.steps):
             step_pcm(args.warmup + k)
+        t_enq = time.perf_counter() - t0         # the host's share: every call above only enqueues
         fe.join()
         barrier()
         dt_local = time.perf_counter() - t0
+        stat["host_enqueue_ms_per_step"] = 1e3 * t_enq / max(args.steps, 1)
         end_stats = fe.device_stats() if DEVICE_ROUNDS else None
         counting[0] = False
         # stage times: a few more steps with HIP events between the stage kernels (outside the timed region: the
@@ -605,6 +607,7 @@ def main():
             st = results["pcm"]["stat"]
             line["config"].update({
                 "blocks_encoded": st["blocks"], "rounds": st["rounds"], "rounds_per_write": st["rounds"] / args.steps,
+                "host_enqueue_ms_per_step": st.get("host_enqueue_ms_per_step"),
                 "rounds_pattern": os.environ.get("VBM_BENCH_ROUNDS", "2,1,1,1"),
                 "outputs_joined_on": ("a consumer stream after every call (the feeding stream never waits for packets)"
                                       if os.environ.get("VBM_BENCH_CONSUMER", "1") != "0" else "the feeding stream (lazy join)"),

@@ -73,19 +73,23 @@ def test_full_size_from_pcm(oracle, cuda, S, K, ch, rate, q, nchunks, multi):
     enc.close()
 
 
-def test_full_size_benchmarked_path(oracle, cuda, monkeypatch):
-    """The path bench.py times, at its size: 16384 stereo q5 streams, rounds built on the device replayed as HIP graphs,
+@pytest.mark.parametrize("bitrate", [None, (144000, 128000, 112000)])
+def test_full_size_benchmarked_path(oracle, cuda, monkeypatch, bitrate):
+    """(Managed-bitrate case: `bench.py --bitrate`'s path — all fifteen packetblobs of a block per launch, the bitrate
+    manager's choice ordered behind the batches before it, two workspaces, 28 writes.)
+    The path bench.py times, at its size: 16384 stereo q5 streams, rounds built on the device replayed as HIP graphs,
     four workspaces, 2, 1, 1, 1 rounds per 1024-sample write (bench.py's default pattern), the feeding stream never tied to the outputs (lazy = 2, a
     consumer stream joins; the first six writes run three rounds each, as the bench's warm-up does, to clear the start of
     the streams where all of them deliver short blocks at once), 64 writes of signals with a noise burst every 40000
     samples (a fifth of the blocks are short ones).  Every stream against its twin (sequence check: a stream may be put off to a later round than its
     twin), the 16 distinct signals against the oracle, end of stream included."""
     import vorbis_aotuv_lancer_amd as v
-    monkeypatch.setenv("VBM_WORKSPACES", "4")
-    S, K, ch, rate, q, nchunks = 16384, 16, 2, 44100, 0.5, 64
-    sigs = [burst_signal(ch, rate, nchunks * 1024, seed=400 + k, period=40000, level=1.0 if k % 5 else 0.05) for k in range(K)]
+    monkeypatch.setenv("VBM_WORKSPACES", "2" if bitrate else "4")
+    S, K, ch, rate, q, nchunks = 16384, 16, 2, 44100, (None if bitrate else 0.5), (28 if bitrate else 64)
+    sigs = [burst_signal(ch, rate, nchunks * 1024, seed=400 + k, period=(12000 if bitrate else 40000), level=1.0 if k % 5 else 0.05)
+            for k in range(K)]
     base = torch.from_numpy(np.stack(sigs)).to(cuda)
-    setup = v.Setup(ch, rate, q)
+    setup = v.Setup(ch, rate, bitrate=bitrate) if bitrate else v.Setup(ch, rate, q)
     lanes = v.lib.vbm_device_round_lanes(setup._h, S)
     enc = v.Encoder(setup, S, max_batch=lanes)
     fe = v.FrontEnd(enc)
@@ -118,7 +122,7 @@ def test_full_size_benchmarked_path(oracle, cuda, monkeypatch):
             break
         led.add_host_round(info, packets, nbytes, "end of stream")
     led.finish("benchmarked path")
-    osetup = orc.Setup(oracle, ch, rate, q)
+    osetup = orc.Setup(oracle, ch, rate, q, bitrate=bitrate)
     for k in range(K):
         assert led.lead_packets(k) == oracle_packets(oracle, osetup, sigs[k], nchunks, finish=True), \
             f"signal {k}: packets differ from the oracle"

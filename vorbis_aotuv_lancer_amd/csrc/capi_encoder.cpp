@@ -933,8 +933,22 @@ static int enqueue_job(vbm_encoder *e, const type_job &j)
                 return vbm_set_hip_error(err, "hipStreamWaitEvent");
     if (!j.grouped) vbm_debug_delay_point(VBM_DP_JOB_STATE, q);
     { TIMED(3, q); RUN(vbm_launch_prologue(&v, q)); }
+    // the long-block batch of a round: tone mask (log spectrum + the prologue's maxima) beside the noise mask (MDCT) on a
+    // second stream, as in the two-stream form (vbm_analysis_batch2); under a stream capture the fork and the join become
+    // edges of the graph.  One such batch is enqueued at a time (rounds are built one after the other): aux[0] is its own.
+    static const int round_branches = getenv("VBM_ROUND_BRANCHES") ? atoi(getenv("VBM_ROUND_BRANCHES")) : 0;   // measured: from PCM 5.04 ms per step with, 4.58 without (the two LDS-heavy kernels side by side crowd out the back half of the round before) — off
+    if (round_branches && e->overlap_branches && !e->aux.empty() && m == 3 && !j.few && (j.big || (j.grouped && j.part == 1))) {
+        hipStream_t qa = e->aux[0];
+        if ((err = hipEventRecord(e->ev_aux_fork[0], q)) != hipSuccess || (err = hipStreamWaitEvent(qa, e->ev_aux_fork[0], 0)) != hipSuccess)
+            return vbm_set_hip_error(err, "tone-mask branch fork");
+        { TIMED(5, qa); RUN(vbm_launch_tonemask(&v, s->psy[v.block_mode].total_octave_lines, qa)); }
+        if ((err = hipEventRecord(e->ev_aux_join[0], qa)) != hipSuccess) return vbm_set_hip_error(err, "hipEventRecord");
+        { TIMED(4, q); RUN(vbm_launch_noisemask(&v, q)); }
+        if ((err = hipStreamWaitEvent(q, e->ev_aux_join[0], 0)) != hipSuccess) return vbm_set_hip_error(err, "tone-mask branch join");
+    } else {
     { TIMED(4, q); RUN(vbm_launch_noisemask(&v, q)); }
     { TIMED(5, q); RUN(vbm_launch_tonemask(&v, s->psy[v.block_mode].total_octave_lines, q)); }
+    }
     { TIMED(6, q);
       if (s->managed) RUN(managed_front(v, q));
       else { RUN(vbm_launch_mix(&v, q)); RUN(vbm_launch_block_state(&v, q)); } }
