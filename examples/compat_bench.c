@@ -35,10 +35,10 @@ typedef struct {
     vorbis_block *vb;
     vorbis_info *vi;
     pthread_barrier_t *bar;
-    const float *pcm;          /* [period][CH] interleaved source, shared */
+    const float *pcm;          /* [CH][period] planar source, shared */
     long period;
     long long bytes, packets, samples;
-    double t0, t1;
+    double t0, t1, t_write, t_drain;
     int failed;
 } worker;
 
@@ -62,17 +62,22 @@ static void *run(void *arg)
             pthread_barrier_wait(w->bar);
             w->t0 = now();
             w->bytes = w->packets = w->samples = 0;
+            w->t_write = w->t_drain = 0;
         }
+        const double ta = now();
         for (int s = 0; s < M; s++) {
             float **buf = vorbis_analysis_buffer(&vd[s], READ);
             /* every stream reads the shared signal at its own offset (streams differ, nothing is generated in the loop) */
-            long at = ((long)(w->id * M + s) * 7919 + (long)k * READ) % w->period;
-            for (int i = 0; i < READ; i++, at = (at + 1 == w->period) ? 0 : at + 1) {
-                buf[0][i] = w->pcm[at * CH];
-                buf[1][i] = w->pcm[at * CH + 1];
+            const long at = ((long)(w->id * M + s) * 7919 + (long)k * READ) % w->period;
+            const long first = (w->period - at < READ) ? w->period - at : READ;
+            for (int c = 0; c < CH; c++) {
+                memcpy(buf[c], w->pcm + c * w->period + at, first * sizeof(float));
+                if (first < READ) memcpy(buf[c] + first, w->pcm + c * w->period, (READ - first) * sizeof(float));
             }
             if (vorbis_analysis_wrote(&vd[s], READ)) { w->failed = 1; break; }
         }
+        const double tb = now();
+        w->t_write += tb - ta;
         for (int s = 0; s < M && !w->failed; s++) {
             while (vorbis_analysis_blockout(&vd[s], &vb[s]) == 1) {
                 if (vorbis_analysis(&vb[s], NULL) || vorbis_bitrate_addblock(&vb[s])) { w->failed = 1; break; }
@@ -84,6 +89,7 @@ static void *run(void *arg)
                 }
             }
         }
+        w->t_drain += now() - tb;
     }
     w->t1 = now();
     pthread_barrier_wait(w->bar);
@@ -113,7 +119,7 @@ int main(int argc, char **argv)
             const double t = (double)i / RATE;
             double x = 0.3 * sin(2 * M_PI * 440.0 * (c + 1) * t) + 0.2 * sin(2 * M_PI * 3000.0 * t + c) + 0.05 * noise;
             if ((i % (RATE * 4 / 3)) < 200) x += 0.6 * noise;
-            pcm[i * CH + c] = (float)x;
+            pcm[c * period + i] = (float)x;
         }
 
     vorbis_info vi;
@@ -146,6 +152,12 @@ int main(int argc, char **argv)
     }
     long long rounds = 0;
     vorbis_mi355x_ctl(VORBIS_MI355X_ROUNDS, &rounds);
+    double lib[8], tw = 0, td = 0;
+    vorbis_mi355x_ctl(VORBIS_MI355X_TIMES, lib);
+    for (int i = 0; i < T; i++) { tw += w[i].t_write; td += w[i].t_drain; }
+    fprintf(stderr, "host seconds (all threads, timed region + warm-up for the library's): app write phase %.3f, drain phase %.3f; "
+            "library: wrote-copy %.3f, staging copies %.3f, upload %.3f, rounds %.3f, compaction + D2H %.3f, filing %.3f\n",
+            tw, td, lib[0], lib[1], lib[2], lib[3], lib[4], lib[5]);
     const double wall = t1 - t0, audio = (double)samples / RATE;
     printf("{\"threads\": %d, \"streams\": %d, \"pool_streams\": %d, \"writes\": %d, \"wall_s\": %.4f, \"value\": %.1f, "
            "\"input_audio_s\": %.1f, \"encoded_audio_s\": %.1f, \"packets\": %lld, \"packet_bytes\": %lld, "

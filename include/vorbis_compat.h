@@ -277,6 +277,9 @@ int vorbis_encode_init(vorbis_info *vi, long channels, long rate, long max_bitra
 #define VORBIS_MI355X_DATA_DIR     3   /* arg const char*: directory of common.vpk / mode_*.vpk (default: data/
                                           beside the library, environment VORBIS_MI355X_DATA) */
 #define VORBIS_MI355X_ROUNDS       4   /* arg long long* (out): device rounds run so far, all pools */
+#define VORBIS_MI355X_TIMES        6   /* arg double[8] (out): seconds of host time, summed over all threads, spent in 0 the copy of
+                                          vorbis_analysis_wrote, 1 staging copies, 2 uploads (H2D, append kernels, waits), 3 device
+                                          rounds, 4 packet compaction + D2H, 5 filing packets per stream */
 #define VORBIS_MI355X_DEFER_BLOCKS 5   /* arg int*: 0 (default) vorbis_analysis_blockout hands out every block the stream has, like the
                                           reference; 1 throughput mode: one block per write (two every third write) unless the
                                           stream's buffer is half full or the stream is ending — a stream inside a run of short

@@ -251,6 +251,12 @@ int vbm_frontend_finish(vbm_frontend *fe, const int *stream_ids, int n, void *st
  * typically after the slot's previous stream has delivered its e_o_s packet). */
 int vbm_frontend_write_streams(vbm_frontend *fe, const int *stream_ids, int n, const float *d_pcm, int vals,
                                void *stream);
+/* The same with the caller's own layout: channel c of stream_ids[k] at pcm + (by_slot ? stream_ids[k] : k) * stream_stride
+ * + c * ch_stride floats (ch_stride >= vals).  pcm may be host memory the device can read (hipHostMalloc): the append
+ * kernel fetches it over the bus itself, no staging copy and no separate upload (what the drop-in shim's
+ * vorbis_analysis_buffer hands out, reference lib/block.c:405-436).  Returns when the samples have been taken. */
+int vbm_frontend_write_streams_strided(vbm_frontend *fe, const int *stream_ids, int n, const float *pcm, int vals,
+                                       long stream_stride, long ch_stride, int by_slot, void *stream);
 int vbm_frontend_restart_streams(vbm_frontend *fe, const int *stream_ids, int n, void *stream);
 /* Buffer occupancy, for callers that do not drain completely after every write (a stream inside a
  * run of short blocks yields up to 8 blocks per 1024 samples, each in its own round): the most
@@ -320,6 +326,10 @@ int vbm_frontend_join(vbm_frontend *fe, void *stream);
 int vbm_device_round_lanes(const vbm_setup_handle *setup, int nstreams);
 int vbm_frontend_encode_rounds_device(vbm_frontend *fe, int nrounds, uint8_t *d_packets, int *d_packet_bytes,
                                       vbm_packet_info *d_info, int *d_counts, int lazy, void *stream);
+/* The block type every stream had ready when the newest device-built round was planned (-1: none), [nstreams] bytes,
+ * copied to `out` (host) on `stream` after the round's outputs: a stream with a type here and no record in the round
+ * found its type's lane region full and delivers the block in the next round. */
+int vbm_frontend_round_types(vbm_frontend *fe, signed char *out, void *stream);
 /* running totals of the device-built rounds: out[0..3] blocks of type 0..3, out[4] samples all streams advanced by,
  * out[5] writes the device refused because a stream's buffer was full (must stay 0: the refused samples are lost —
  * the device-side counterpart of vbm_frontend_write's VBM_EINVAL).  Synchronises the front end's stream. */

@@ -71,6 +71,9 @@ SIGNATURES = {
     "vbm_frontend_write": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vbm_frontend_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vbm_frontend_write_streams": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "vbm_frontend_round_types": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vbm_frontend_write_streams_strided": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_long, C.c_long,
+                                                     C.c_int, C.c_void_p]),
     "vbm_frontend_restart_streams": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vbm_frontend_max_buffered": (C.c_int, [C.c_void_p]),
     "vbm_frontend_capacity": (C.c_int, [C.c_void_p]),

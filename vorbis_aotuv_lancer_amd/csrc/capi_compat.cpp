@@ -16,8 +16,11 @@
 #include <stdlib.h>
 #include <string.h>
 #include <strings.h>
+#include <atomic>
+#include <chrono>
 #include <deque>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -40,14 +43,17 @@ struct cblock {                      // one carved and encoded block (vb->intern
 
 struct cwrite {                      // one vorbis_analysis_wrote, not yet on the device
     int vals;
-    std::vector<float> data;         // [ch][vals]
+    bool in_arena = false;           // the samples sit in the stream's slot of the pool's staging arena (no copy was made)
+    std::vector<float> data;         // [ch][vals] otherwise
 };
 
 struct cstream {                     // vd->backend_state
     cpool *pool = nullptr;
     int slot = -1;
-    std::vector<float> hostbuf;      // what vorbis_analysis_buffer hands out: [ch][buf_vals]
+    std::vector<float> hostbuf;      // what vorbis_analysis_buffer hands out when the arena cannot serve: [ch][buf_vals]
     int buf_vals = 0;
+    bool buf_in_arena = false;       // the pointers handed out last point into the pool's arena
+    std::atomic<bool> arena_pending{false};   // the slot's arena region holds a write that has not gone up yet
     std::vector<float *> ptrs;
     std::deque<cwrite> writes;
     bool eof_asked = false;          // vorbis_analysis_wrote(v, 0) seen, not yet on the device
@@ -75,11 +81,22 @@ struct cpool {
     std::vector<cstream *> slots;
     std::vector<char> used_before;   // a stream has lived in the slot: the next one restarts it
     hipStream_t q = nullptr;
-    float *h_pcm = nullptr, *d_pcm = nullptr;   // staging of one group of writes
+    float *h_pcm = nullptr, *d_pcm = nullptr;   // staging of one group of writes (those that did not go through the arena)
+    // Staging arena: pinned host memory the device reads directly, [slot][ch][arena_vals].  vorbis_analysis_buffer hands
+    // out the stream's own region (as the reference hands out its own PCM buffer, lib/block.c:405-436), so that
+    // vorbis_analysis_wrote copies nothing and the upload is the append kernel fetching over the bus.
+    float *arena = nullptr;
+    int arena_vals = 0;
     size_t pcm_floats = 0;
     uint8_t *d_pkt = nullptr, *d_cmp = nullptr, *h_cmp = nullptr;
     int *d_len = nullptr, *h_len = nullptr;
     long long *d_off = nullptr, *h_off = nullptr;
+    // rounds built on the device (vbm_frontend_encode_rounds_device: no decision comes back to the host in the middle of a
+    // round, the kernels replay as HIP graphs): `lanes` output rows per round, records and the streams' ready types read back
+    int lanes = 0;                   // 0: host-built rounds
+    vbm_packet_info *d_info = nullptr, *h_info = nullptr;
+    int *d_counts = nullptr;
+    signed char *h_types = nullptr;
     size_t h_cmp_bytes = 0;
     std::vector<vbm_packet_info> info;
     int capacity = 0;                // samples a stream's device buffer may hold (vbm_frontend_capacity)
@@ -104,6 +121,15 @@ int g_carve_ahead = 1;
 int g_defer_blocks = -1;             // -1: environment VORBIS_MI355X_DEFER_BLOCKS, default 0
 std::string g_data_dir;
 long long g_rounds = 0;
+// where the host's time goes (VORBIS_MI355X_TIMES): seconds summed over all threads —
+// 0 vorbis_analysis_wrote's copy, 1 staging copies of an upload, 2 upload: H2D + append kernels + waits, 3 the device
+// round (decisions read back, kernels enqueued), 4 packet compaction + D2H waits, 5 filing packets per stream
+std::atomic<long long> g_ns[8];
+struct span_timer {
+    int k; std::chrono::steady_clock::time_point t0;
+    explicit span_timer(int k_) : k(k_), t0(std::chrono::steady_clock::now()) {}
+    ~span_timer() { g_ns[k] += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
+};
 
 std::string data_dir()
 {
@@ -137,6 +163,7 @@ void pool_destroy(cpool *p)
     if (p->fe) vbm_frontend_destroy(p->fe);
     if (p->enc) vbm_encoder_destroy(p->enc);
     if (p->h_pcm) (void)hipHostFree(p->h_pcm);
+    if (p->arena) (void)hipHostFree(p->arena);
     if (p->d_pcm) (void)hipFree(p->d_pcm);
     if (p->d_pkt) (void)hipFree(p->d_pkt);
     if (p->d_cmp) (void)hipFree(p->d_cmp);
@@ -145,6 +172,10 @@ void pool_destroy(cpool *p)
     if (p->h_len) (void)hipHostFree(p->h_len);
     if (p->d_off) (void)hipFree(p->d_off);
     if (p->h_off) (void)hipHostFree(p->h_off);
+    if (p->d_info) (void)hipFree(p->d_info);
+    if (p->h_info) (void)hipHostFree(p->h_info);
+    if (p->d_counts) (void)hipFree(p->d_counts);
+    if (p->h_types) (void)hipHostFree(p->h_types);
     if (p->q) (void)hipStreamDestroy(p->q);
     delete p;
 }
@@ -154,13 +185,31 @@ cpool *pool_create(cclass *c)
     cpool *p = new cpool();
     p->cls = c;
     p->S = pool_streams();
-    if (vbm_encoder_create(&p->enc, c->setup, p->S, p->S) || vbm_frontend_create(&p->fe, p->enc)) {
+    {
+        // VORBIS_MI355X_DEVICE_ROUNDS=1: the pool's rounds are built on the device (no decision read back in the middle of
+        // a round, HIP graphs).  Off by default: a pool round here is a few thousand blocks at most and often a handful
+        // (the reference's delivery asks for a round per short block), and a device-built round launches every block type's
+        // whole lane region whatever it holds — measured 4 x 4096 streams: 19 k streams at 1x against 21-25 k (deferred
+        // delivery), 5.3 k against 10.3 k (reference delivery).
+        const char *env = getenv("VORBIS_MI355X_DEVICE_ROUNDS");
+        if (env && atoi(env)) p->lanes = vbm_device_round_lanes(c->setup, p->S);
+        if (p->lanes < 0) p->lanes = 0;
+    }
+    if (vbm_encoder_create(&p->enc, c->setup, p->S, p->lanes ? p->lanes : p->S) || vbm_frontend_create(&p->fe, p->enc)) {
         pool_destroy(p);
         return nullptr;
     }
     p->maxb = vbm_encoder_max_packet_bytes(p->enc);
     p->capacity = vbm_frontend_capacity(p->fe);
-    const size_t S = (size_t)p->S;
+    const size_t S = (size_t)(p->lanes ? p->lanes : p->S);      // output rows of a round
+    if (p->lanes &&
+        (hipMalloc((void **)&p->d_info, S * sizeof(vbm_packet_info)) != hipSuccess ||
+         hipHostMalloc((void **)&p->h_info, S * sizeof(vbm_packet_info), hipHostMallocDefault) != hipSuccess ||
+         hipMalloc((void **)&p->d_counts, 4 * sizeof(int)) != hipSuccess ||
+         hipHostMalloc((void **)&p->h_types, (size_t)p->S, hipHostMallocDefault) != hipSuccess)) {
+        pool_destroy(p);
+        return nullptr;
+    }
     if (hipStreamCreateWithFlags(&p->q, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void **)&p->d_pkt, S * p->maxb) != hipSuccess || hipMalloc((void **)&p->d_cmp, S * p->maxb) != hipSuccess ||
         hipMalloc((void **)&p->d_len, S * sizeof(int)) != hipSuccess ||
@@ -170,9 +219,20 @@ cpool *pool_create(cclass *c)
         pool_destroy(p);
         return nullptr;
     }
+    {
+        // VORBIS_MI355X_ARENA_VALS: samples per channel a stream's arena region holds (default 1024 = the write size of the
+        // reference's examples; larger requests are served from ordinary memory and copied); 0: no arena
+        const char *env = getenv("VORBIS_MI355X_ARENA_VALS");
+        p->arena_vals = env ? atoi(env) : 1024;
+        if (p->arena_vals > 0 &&
+            hipHostMalloc((void **)&p->arena, (size_t)p->S * c->ch * (size_t)p->arena_vals * sizeof(float), hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
+            p->arena = nullptr;
+            p->arena_vals = 0;
+        }
+    }
     p->slots.assign(p->S, nullptr);
     p->used_before.assign(p->S, 0);
-    p->info.resize(p->S);
+    p->info.resize(S);
     p->buffered.assign(p->S, c->bs[1] / 2);     // centerW of a fresh stream (lib/block.c:330)
     return p;
 }
@@ -195,11 +255,19 @@ int pool_stage(cpool *p, size_t floats)
 int pool_round(cpool *p, cstream *only, bool restrict_to_only, bool *got_only)
 {
     int n = 0, rc;
+    const bool dev = p->lanes > 0 && !restrict_to_only;     // the round is built on the device: rows = lanes, empty ones marked -2
+    const vbm_packet_info *info = dev ? p->h_info : p->info.data();
+    {
+    span_timer tm(3);
     if (restrict_to_only) {
         const int id = only->slot;
         rc = vbm_frontend_encode_round_streams(p->fe, &id, 1, p->d_pkt, p->d_len, p->info.data(), &n, p->q);
+    } else if (dev) {
+        rc = vbm_frontend_encode_rounds_device(p->fe, 1, p->d_pkt, p->d_len, p->d_info, p->d_counts, 0, p->q);
+        n = p->lanes;
     } else {
         rc = vbm_frontend_encode_round(p->fe, p->d_pkt, p->d_len, p->info.data(), &n, p->q);
+    }
     }
     {
         std::lock_guard<std::mutex> lk(g_mu);
@@ -208,18 +276,23 @@ int pool_round(cpool *p, cstream *only, bool restrict_to_only, bool *got_only)
     if (got_only) *got_only = false;
     if (rc) return rc;
     // a stream the round had no block for has nothing more to give until it is written to again: its next
-    // vorbis_analysis_blockout is answered without a device round
+    // vorbis_analysis_blockout is answered without a device round.  (Device-built rounds: unless it had a block ready and
+    // found its type's lane region full — h_types says so — in which case the next round delivers it.)
     auto settle = [&](int nb) {
         if (restrict_to_only) return;
         std::vector<char> had(p->S, 0);
-        for (int k = 0; k < nb; k++) had[p->info[k].stream] = 1;
+        for (int k = 0; k < nb; k++)
+            if (!dev || p->h_len[k] != -2) had[info[k].stream] = 1;
         for (int i = 0; i < p->S; i++)
-            if (p->slots[i] && !had[i] && p->slots[i]->writes.empty()) p->slots[i]->dirty = false;
+            if (p->slots[i] && !had[i] && p->slots[i]->writes.empty() && !(dev && p->h_types[i] >= 0)) p->slots[i]->dirty = false;
     };
     if (n == 0) { settle(0); return 0; }
+    std::unique_ptr<span_timer> tm4(new span_timer(4));
     if (vbm_packets_compact(p->d_pkt, p->d_len, n, p->maxb, p->d_cmp, p->d_off, p->q)) return OV_EFAULT;
     if (hipMemcpyAsync(p->h_len, p->d_len, n * sizeof(int), hipMemcpyDeviceToHost, p->q) != hipSuccess ||
         hipMemcpyAsync(p->h_off, p->d_off, (n + 1) * sizeof(long long), hipMemcpyDeviceToHost, p->q) != hipSuccess ||
+        (dev && (hipMemcpyAsync(p->h_info, p->d_info, (size_t)n * sizeof(vbm_packet_info), hipMemcpyDeviceToHost, p->q) != hipSuccess ||
+                 vbm_frontend_round_types(p->fe, p->h_types, p->q))) ||
         hipStreamSynchronize(p->q) != hipSuccess) return OV_EFAULT;
     const size_t total = (size_t)p->h_off[n];
     if (total > p->h_cmp_bytes) {
@@ -232,9 +305,13 @@ int pool_round(cpool *p, cstream *only, bool restrict_to_only, bool *got_only)
     }
     if (total && (hipMemcpyAsync(p->h_cmp, p->d_cmp, total, hipMemcpyDeviceToHost, p->q) != hipSuccess ||
                   hipStreamSynchronize(p->q) != hipSuccess)) return OV_EFAULT;
+    tm4.reset();
+    span_timer tm5(5);
     const int bs0 = p->cls->bs[0], bs1 = p->cls->bs[1];
     for (int k = 0; k < n; k++) {
-        const vbm_packet_info &pi = p->info[k];
+        if (dev && p->h_len[k] == -2) continue;       // a lane without a block
+        const vbm_packet_info &pi = info[k];
+        if (pi.stream < 0 || pi.stream >= p->S) return OV_EFAULT;
         cstream *s = p->slots[pi.stream];
         if (p->h_len[k] < 0) return OV_EFAULT;        // a packet outgrew max_packet_bytes: never silently truncated
         // host mirror of the buffer fill: the buffer moves down by the distance between block centres
@@ -284,16 +361,37 @@ int pool_upload(cpool *p, cstream *only)
         }
         for (auto &g : groups) {
             const int vals = g.first;
-            std::vector<cstream *> &ss = g.second;
+            std::vector<cstream *> direct, copied;
+            for (cstream *s : g.second) (s->writes.front().in_arena ? direct : copied).push_back(s);
+            if (!direct.empty()) {
+                // straight from the arena: the append kernel reads the slots' regions over the bus
+                span_timer tm2(2);
+                std::vector<int> ids(direct.size());
+                for (size_t k = 0; k < direct.size(); k++) ids[k] = direct[k]->slot;
+                int rc = vbm_frontend_write_streams_strided(p->fe, ids.data(), (int)ids.size(), p->arena, vals,
+                                                            (long)ch * p->arena_vals, p->arena_vals, 1, p->q);
+                if (rc) return rc;
+                for (cstream *s : direct) {          // (the call returns when the samples have been taken)
+                    p->buffered[s->slot] += vals;
+                    s->writes.pop_front();
+                    s->arena_pending = false;
+                }
+            }
+            if (copied.empty()) continue;
+            std::vector<cstream *> &ss = copied;
             const size_t per = (size_t)ch * vals;
             int rc = pool_stage(p, per * ss.size());
             if (rc) return rc;
             std::vector<int> ids(ss.size());
             (void)hipStreamSynchronize(p->q);                         // the staging buffer is free again
+            {
+            span_timer tm(1);
             for (size_t k = 0; k < ss.size(); k++) {
                 ids[k] = ss[k]->slot;
                 memcpy(p->h_pcm + k * per, ss[k]->writes.front().data.data(), per * sizeof(float));
             }
+            }
+            span_timer tm2(2);
             if (hipMemcpyAsync(p->d_pcm, p->h_pcm, per * ss.size() * sizeof(float), hipMemcpyHostToDevice, p->q) != hipSuccess)
                 return OV_EFAULT;
             rc = vbm_frontend_write_streams(p->fe, ids.data(), (int)ids.size(), p->d_pcm, vals, p->q);
@@ -400,6 +498,9 @@ extern "C" int vorbis_mi355x_ctl(int request, void *arg)
     case VORBIS_MI355X_DEFER_BLOCKS: g_defer_blocks = *(int *)arg != 0; return 0;
     case VORBIS_MI355X_DATA_DIR: g_data_dir = (const char *)arg; return 0;
     case VORBIS_MI355X_ROUNDS: *(long long *)arg = g_rounds; return 0;
+    case VORBIS_MI355X_TIMES:
+        for (int i = 0; i < 8; i++) ((double *)arg)[i] = 1e-9 * (double)g_ns[i].load();
+        return 0;
     }
     return OV_EINVAL;
 }
@@ -618,7 +719,17 @@ extern "C" float **vorbis_analysis_buffer(vorbis_dsp_state *v, int vals)
 {
     cstream *s = stream_of(v);
     if (!s || vals < 0) return nullptr;
-    const int ch = s->pool->cls->ch;
+    cpool *p = s->pool;
+    const int ch = p->cls->ch;
+    if (p->arena && vals <= p->arena_vals && !s->arena_pending.load()) {
+        // the stream's own region of the pool's pinned staging arena (free: its last write has gone up)
+        for (int c = 0; c < ch; c++) s->ptrs[c] = p->arena + ((size_t)s->slot * ch + c) * p->arena_vals;
+        s->buf_in_arena = true;
+        v->pcmret = s->ptrs.data();
+        v->pcm_storage = p->arena_vals;
+        return v->pcmret;
+    }
+    s->buf_in_arena = false;
     if (vals > s->buf_vals) {
         s->buf_vals = vals * 2 > 1024 ? vals * 2 : 1024;
         s->hostbuf.assign((size_t)ch * s->buf_vals, 0.f);
@@ -646,11 +757,17 @@ extern "C" int vorbis_analysis_wrote(vorbis_dsp_state *v, int vals)
         int rc = stream_send_eof(p, s);
         return rc ? OV_EINVAL : 0;
     }
-    if (vals > s->buf_vals) return OV_EINVAL;    // more than vorbis_analysis_buffer handed out (lib/block.c:540-541)
+    if (vals > (s->buf_in_arena ? p->arena_vals : s->buf_vals)) return OV_EINVAL;    // more than vorbis_analysis_buffer handed out (lib/block.c:540-541)
+    span_timer tm(0);
     cwrite w;
     w.vals = vals;
-    w.data.resize((size_t)c->ch * vals);
-    for (int k = 0; k < c->ch; k++) memcpy(w.data.data() + (size_t)k * vals, s->ptrs[k], vals * sizeof(float));
+    if (s->buf_in_arena && !s->arena_pending.load()) {
+        w.in_arena = true;                       // the samples stay where the application put them
+        s->arena_pending = true;
+    } else {
+        w.data.resize((size_t)c->ch * vals);
+        for (int k = 0; k < c->ch; k++) memcpy(w.data.data() + (size_t)k * vals, s->ptrs[k], vals * sizeof(float));
+    }
     s->writes.push_back(std::move(w));
     s->dirty = true;
     s->given_since_write = 0;

@@ -318,7 +318,18 @@ static int upload_ids(vbm_frontend *fe, const int *stream_ids, int n, hipStream_
 extern "C" int vbm_frontend_write_streams(vbm_frontend *fe, const int *stream_ids, int n, const float *d_pcm, int vals,
                                           void *stream)
 {
-    if (!fe || n < 0 || (n && (!stream_ids || !d_pcm)) || vals <= 0) return VBM_EINVAL;
+    if (!fe) return VBM_EINVAL;
+    return vbm_frontend_write_streams_strided(fe, stream_ids, n, d_pcm, vals, (long)fe->ch * vals, vals, 0, stream);
+}
+
+// the same with the source laid out by the caller: channel c of stream_ids[k] at pcm + (by_slot ? stream_ids[k] : k) *
+// stream_stride + c * ch_stride floats.  pcm: device memory, or host memory the device can read (hipHostMalloc): the
+// append kernel then fetches it over the bus itself — no staging copy, no separate upload.  The call returns when the
+// samples have been taken (the source may be rewritten).
+extern "C" int vbm_frontend_write_streams_strided(vbm_frontend *fe, const int *stream_ids, int n, const float *d_pcm, int vals,
+                                                  long stream_stride, long ch_stride, int by_slot, void *stream)
+{
+    if (!fe || n < 0 || (n && (!stream_ids || !d_pcm)) || vals <= 0 || ch_stride < vals || stream_stride < 0) return VBM_EINVAL;
     if (n == 0) return VBM_OK;
     const vbm_setup *s = fe->hs;
     const int bs1 = s->blocksizes[1];
@@ -338,7 +349,7 @@ extern "C" int vbm_frontend_write_streams(vbm_frontend *fe, const int *stream_id
     if (rc) return rc;
     rc = upload_ids(fe, stream_ids, n, st);
     if (rc) return rc;
-    if (vbm_fe_launch_append_ids(&fe->f, fe->d_ids, n, d_pcm, vals, s->pre_amplitude, st)) return VBM_EHIP;
+    if (vbm_fe_launch_append_ids(&fe->f, fe->d_ids, n, d_pcm, vals, s->pre_amplitude, stream_stride, ch_stride, by_slot, st)) return VBM_EHIP;
     bool cross = false;
     for (int k = 0; k < n; k++) {
         const int i = stream_ids[k];
@@ -790,6 +801,15 @@ extern "C" int vbm_frontend_encode_rounds_device(vbm_frontend *fe, int nrounds, 
     fe->mirrors_stale = true;
     if (lazy == 2) return VBM_OK;          // the consumer joins (vbm_frontend_join on its own stream)
     return lazy ? vbm_analysis_round_join_lazy(fe->enc, stream) : vbm_analysis_round_join(fe->enc, stream);
+}
+
+// which block type every stream had ready when the newest device-built round was planned (-1: none) — a stream with a
+// type here and no entry in the round's records found its type's lane region full and keeps the block for the next round
+extern "C" int vbm_frontend_round_types(vbm_frontend *fe, signed char *out, void *stream)
+{
+    if (!fe || !out || !fe->d_type) return VBM_EINVAL;
+    hipError_t err = hipMemcpyAsync(out, fe->d_type, (size_t)fe->S, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    return err == hipSuccess ? VBM_OK : vbm_set_hip_error(err, "hipMemcpyAsync(round types)");
 }
 
 // running totals of the rounds built on the device: blocks of type 0..3 and the samples all streams advanced by

@@ -6,7 +6,7 @@
 extern "C" {
 int vbm_fe_launch_append(const vbm_fe_state *f, const float *d_src, int vals, float pre_amplitude, hipStream_t st);
 int vbm_fe_launch_append_ids(const vbm_fe_state *f, const int *d_ids, int n, const float *d_src, int vals,
-                             float pre_amplitude, hipStream_t st);
+                             float pre_amplitude, long stream_stride, long ch_stride, int by_slot, hipStream_t st);
 int vbm_fe_launch_restart(const vbm_fe_state *f, const int *d_ids, int n, int long_n, hipStream_t st);
 int vbm_fe_launch_extrapolate(const vbm_fe_state *f, const int *d_ids, int nids, int mode, int long_n, hipStream_t st);
 int vbm_fe_launch_ve_range(const vbm_fe_state *f, hipStream_t st);

@@ -63,17 +63,30 @@ __global__ void k_fe_commit(vbm_fe_state f, int vals)
     f.pcm_current[s] += vals;
 }
 
-// the same for a subset of the streams: src holds [k][ch][vals] for stream ids[k]
+// the same for a subset of the streams: channel c of stream ids[k] comes from src + (by_slot ? ids[k] : k) * stream_stride
+// + c * ch_stride (plain [k][ch][vals]: strides ch * vals and vals).  src may be pinned host memory (the drop-in shim's
+// staging arena, read over the bus by this kernel: 16 bytes per thread and step when everything is aligned)
 __global__ void k_fe_append_ids(vbm_fe_state f, const int *__restrict__ ids, const float *__restrict__ src, int vals,
-                                float pre_amplitude)
+                                float pre_amplitude, long stream_stride, long ch_stride, int by_slot)
 {
     const int kc = blockIdx.x;                      // listed stream k, channel c
     const int k = kc / f.ch, c = kc % f.ch;
     const int s = ids[k];
     if (f.base[s] + f.pcm_current[s] + vals > f.cap) return;
     float *dst = f.pcm + (long)f.parity[s] * f.plane + ((long)s * f.ch + c) * f.cap + f.base[s] + f.pcm_current[s];
-    const float *in = src + (long)kc * vals;
-    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < vals; i += gridDim.y * blockDim.x)
+    const float *in = src + (long)(by_slot ? s : k) * stream_stride + (long)c * ch_stride;
+    const int t0 = blockIdx.y * blockDim.x + threadIdx.x, step = gridDim.y * blockDim.x;
+    if ((((uintptr_t)dst | (uintptr_t)in) & 15) == 0 && (vals & 3) == 0) {
+        const float4 *in4 = reinterpret_cast<const float4 *>(in);
+        float4 *dst4 = reinterpret_cast<float4 *>(dst);
+        for (int i = t0; i < vals / 4; i += step) {
+            float4 v = in4[i];
+            v.x *= pre_amplitude; v.y *= pre_amplitude; v.z *= pre_amplitude; v.w *= pre_amplitude;   // lib/block.c:514-518
+            dst4[i] = v;
+        }
+        return;
+    }
+    for (int i = t0; i < vals; i += step)
         dst[i] = in[i] * pre_amplitude;
 }
 
@@ -824,12 +837,12 @@ extern "C" int vbm_fe_launch_append(const vbm_fe_state *f, const float *d_src, i
 }
 
 extern "C" int vbm_fe_launch_append_ids(const vbm_fe_state *f, const int *d_ids, int n, const float *d_src, int vals,
-                                        float pre_amplitude, hipStream_t st)
+                                        float pre_amplitude, long stream_stride, long ch_stride, int by_slot, hipStream_t st)
 {
     if (n <= 0) return 0;
-    const unsigned gy = (unsigned)((vals + 255) / 256);
+    const unsigned gy = (unsigned)((vals + 1023) / 1024);
     hipLaunchKernelGGL(k_fe_append_ids, dim3((unsigned)(n * f->ch), gy ? gy : 1), dim3(256), 0, st, *f, d_ids, d_src, vals,
-                       pre_amplitude);
+                       pre_amplitude, stream_stride, ch_stride, by_slot);
     hipLaunchKernelGGL(k_fe_commit_ids, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, *f, d_ids, n, vals);
     return CHECK_LAUNCH();
 }
