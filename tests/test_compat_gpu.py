@@ -85,13 +85,15 @@ def rounds(dll):
     return n.value
 
 
-@pytest.mark.parametrize("defer", [0, 1])
-def test_many_streams_through_the_reference_api(oracle, cuda, dll, defer):
-    """24 stereo q5 streams, each with its own vorbis_info / vorbis_dsp_state / vorbis_block, fed and drained in
+@pytest.mark.parametrize("defer,device_rounds", [(0, 0), (1, 0), (0, 1), (1, 1)])
+def test_many_streams_through_the_reference_api(oracle, cuda, dll, defer, device_rounds, monkeypatch):
+    """(device_rounds = 1: VORBIS_MI355X_DEVICE_ROUNDS, the pool's rounds built on the device and replayed as HIP graphs.)
+    24 stereo q5 streams, each with its own vorbis_info / vorbis_dsp_state / vorbis_block, fed and drained in
     the application's order; streams of different length (end of stream at different times).  defer = 1:
     VORBIS_MI355X_DEFER_BLOCKS, the throughput mode (a block may be handed out later than the reference would; the
     packets and their order per stream are the same)."""
     ch, rate, q, NS = 2, 44100, 0.5, 24
+    monkeypatch.setenv("VORBIS_MI355X_DEVICE_ROUNDS", str(device_rounds))      # (read when a pool is made)
     pool = C.c_int(32)
     dll.vorbis_mi355x_ctl(1, C.byref(pool))
     dflag = C.c_int(defer)

@@ -318,9 +318,13 @@ def test_frontend_reproduces_reference_120s_len_crc(oracle, cuda):
     assert np.array_equal(mine, ref)
 
 
-def test_streams_out_of_lock_step(oracle, cuda):
+@pytest.mark.parametrize("layout", ["plain", "device arena", "pinned host arena"])
+def test_streams_out_of_lock_step(oracle, cuda, layout):
     """Slots that start late, run at their own pace, end and are reused (vbm_frontend_write_streams /
-    _restart_streams): every logical stream still equals the oracle run on its own."""
+    _restart_streams): every logical stream still equals the oracle run on its own.  The arena layouts go through
+    vbm_frontend_write_streams_strided: every slot has its own [channels][2048] region, indexed by slot, in device memory
+    or in pinned host memory that the append kernel reads over the bus (what the drop-in shim's vorbis_analysis_buffer
+    hands out)."""
     import vorbis_aotuv_lancer_amd as v
     ch, rate, q = 2, 44100, 0.5
     osetup = orc.Setup(oracle, ch, rate, q)
@@ -343,6 +347,12 @@ def test_streams_out_of_lock_step(oracle, cuda):
     fe = v.FrontEnd(enc)
     got = [[] for _ in range(4)]
     logical = {}
+    A = 2048
+    arena = None
+    if layout == "device arena":
+        arena = torch.zeros((4, ch, A), dtype=torch.float32, device=cuda)
+    elif layout == "pinned host arena":
+        arena = torch.zeros((4, ch, A), dtype=torch.float32).pin_memory()
 
     def feed(slots_and_names, chunk):
         ids, pcs = [], []
@@ -351,8 +361,13 @@ def test_streams_out_of_lock_step(oracle, cuda):
                 ids.append(slot)
                 pcs.append(sig[name][:, chunk[name] * 1024:(chunk[name] + 1) * 1024])
                 chunk[name] += 1
-        if ids:
+        if ids and arena is None:
             fe.write_streams(ids, torch.from_numpy(np.stack(pcs)).to(cuda).contiguous())
+        elif ids:
+            for slot, pc in zip(ids, pcs):
+                arena[slot, :, :1024] = torch.from_numpy(np.ascontiguousarray(pc)).to(arena.device)
+            torch.cuda.synchronize()
+            fe.write_streams_strided(ids, arena, 1024, ch * A, A, by_slot=True)      # (returns when the samples are taken)
         drain(fe, got)
 
     chunk = {k: 0 for k in sig}

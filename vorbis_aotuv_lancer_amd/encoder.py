@@ -191,6 +191,15 @@ class FrontEnd:
         check(lib.vbm_frontend_write_streams(self._h, ids.ctypes.data, len(ids), pcm.data_ptr(), int(pcm.shape[2]), st),
               "vbm_frontend_write_streams")
 
+    def write_streams_strided(self, stream_ids, pcm, vals, stream_stride, ch_stride, by_slot=False):
+        """vbm_frontend_write_streams_strided: channel c of stream_ids[k] at pcm + (stream_ids[k] if by_slot else k) *
+        stream_stride + c * ch_stride floats; pcm: a CUDA float32 tensor (or pinned host memory the device can read)."""
+        ids = np.ascontiguousarray(stream_ids, dtype=np.int32)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(lib.vbm_frontend_write_streams_strided(self._h, ids.ctypes.data, len(ids), pcm.data_ptr(), int(vals),
+                                                     int(stream_stride), int(ch_stride), int(bool(by_slot)), st),
+              "vbm_frontend_write_streams_strided")
+
     def restart_streams(self, stream_ids):
         """a new stream starts in each listed slot"""
         ids = np.ascontiguousarray(stream_ids, dtype=np.int32)
