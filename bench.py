@@ -546,6 +546,18 @@ def main():
             roofline["kernels"] = STAGE_KERNELS.get(dominant, [])
             roofline["in_situ_ms_per_step"] = per_step.get(dominant)
             roofline["launches_per_step"] = 1
+            if args.bitrate and dominant == "pack":
+                # managed bitrate: the stage timer "pack" brackets the whole back half of a block — floor encode, couple /
+                # quantise and packet assembly of all fifteen packetblobs (capi_encoder.cpp: managed_back) and the choice
+                blobs = 15
+                alg = blobs * (STAGE_BYTES["floor_encode"] + STAGE_BYTES["couple_quantize"] + STAGE_BYTES["pack"]) * ncb
+                ach = alg / (solo[dominant] * 1e-3) / 1e9
+                roofline.update({"kernel": "managed back half (floor encode + couple/quantise + pack, 15 packetblobs)",
+                                 "algorithmic_bytes_per_launch": alg, "achieved": ach, "frac": ach / HBM_PEAK_GBPS, "traffic": None,
+                                 "kernels": STAGE_KERNELS["floor_encode"] + STAGE_KERNELS["couple_quantize"] + STAGE_KERNELS["pack"]
+                                            + ["k_bitrate_choose", "k_blob_gather"],
+                                 "note": "bound by instruction issue, not HBM: k_couple_fast (15 blobs in one launch) and k_res_vq "
+                                         "are 9 of the step's 17.6 ms and run at 60-80 % of the vector issue rate (DESIGN.md 6a)"})
         elif dominant:
             roofline = roof_of(dominant, per_launch[dominant], cb, traffic)
         else:
