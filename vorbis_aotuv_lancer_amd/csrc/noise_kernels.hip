@@ -42,20 +42,13 @@
 #define VMAX(x, y) ((x) < (y) ? (y) : (x))
 #define NM_PAD 4          /* floats between consecutive LDS arrays: the scan's lanes (one array each) hit different banks */
 #define NM_THREADS 256
-// Unpadded form (SWZ): the five sums of NB blocks are exactly 40960 bytes — a quarter of a CU's LDS, four workgroups per CU
-// instead of three (41120 bytes with the padding; the kernel's time goes with 1 / workgroups per CU: 0.73 ms at three,
-// 0.96 at two, 1.74 at one, tools/gpu_noise_occ.sh).  Without padding the ten scan lanes would all hit one bank, so array
-// a of block blk keeps row k at k ^ NM_X(a + 5 blk): a multiple of four below 64, which permutes the float4 groups inside
-// every aligned run of 64 rows and leaves the scan's 16-byte accesses whole.
-#define NM_X(ab) (4 * ((ab) & 15))
 
 namespace {
 
 struct hy_abd { float A, B, D; };
 
 // the five addends of bin k (lib/psy.c:3497-3507 first element, :3509-3541 the rest)
-template <bool SWZ>
-__device__ __forceinline__ void nm_terms(const float v, const int k, const float offset, float *__restrict__ S, const int NS, const int xb)
+__device__ __forceinline__ void nm_terms(const float v, const int k, const float offset, float *__restrict__ S, const int NS)
 {
     float y = v + offset;
     if (y < 1.f) y = 1.f;
@@ -68,37 +61,19 @@ __device__ __forceinline__ void nm_terms(const float v, const int k, const float
         const float x = (float)k;          // the source's x += 1.f from 0 is exact below 2^24
         t1 = w * x; t2 = w * x * x; t4 = w * x * y;
     }
-    if (SWZ) {
-        S[k ^ NM_X(xb)] = w;
-        S[NS + (k ^ NM_X(xb + 1))] = t1;
-        S[2 * NS + (k ^ NM_X(xb + 2))] = t2;
-        S[3 * NS + (k ^ NM_X(xb + 3))] = w * y;
-        S[4 * NS + (k ^ NM_X(xb + 4))] = t4;
-    } else {
-        S[k] = w;
-        S[NS + k] = t1;
-        S[2 * NS + k] = t2;
-        S[3 * NS + k] = w * y;
-        S[4 * NS + k] = t4;
-    }
+    S[k] = w;
+    S[NS + k] = t1;
+    S[2 * NS + k] = t2;
+    S[3 * NS + k] = w * y;
+    S[4 * NS + k] = t4;
 }
 
 // window sums and regression terms (lib/psy.c:3549-3560 mirrored, :3571-3582 plain); mirrored: the lower edge is row -lo
-template <bool SWZ>
-__device__ __forceinline__ hy_abd nm_window(const float *__restrict__ S, const int NS, const int lo, const int hi, const bool mirror,
-                                            const int xb)
+__device__ __forceinline__ hy_abd nm_window(const float *__restrict__ S, const int NS, const int lo, const int hi, const bool mirror)
 {
     const int l = mirror ? -lo : lo;
-    float Hn, Hx, Hxx, Hy, Hxy, Ln, Lx, Lxx, Ly, Lxy;
-    if (SWZ) {
-        Hn = S[hi ^ NM_X(xb)]; Hx = S[NS + (hi ^ NM_X(xb + 1))]; Hxx = S[2 * NS + (hi ^ NM_X(xb + 2))];
-        Hy = S[3 * NS + (hi ^ NM_X(xb + 3))]; Hxy = S[4 * NS + (hi ^ NM_X(xb + 4))];
-        Ln = S[l ^ NM_X(xb)]; Lx = S[NS + (l ^ NM_X(xb + 1))]; Lxx = S[2 * NS + (l ^ NM_X(xb + 2))];
-        Ly = S[3 * NS + (l ^ NM_X(xb + 3))]; Lxy = S[4 * NS + (l ^ NM_X(xb + 4))];
-    } else {
-        Hn = S[hi]; Hx = S[NS + hi]; Hxx = S[2 * NS + hi]; Hy = S[3 * NS + hi]; Hxy = S[4 * NS + hi];
-        Ln = S[l]; Lx = S[NS + l]; Lxx = S[2 * NS + l]; Ly = S[3 * NS + l]; Lxy = S[4 * NS + l];
-    }
+    const float Hn = S[hi], Hx = S[NS + hi], Hxx = S[2 * NS + hi], Hy = S[3 * NS + hi], Hxy = S[4 * NS + hi];
+    const float Ln = S[l], Lx = S[NS + l], Lxx = S[2 * NS + l], Ly = S[3 * NS + l], Lxy = S[4 * NS + l];
     float tN, tX, tXX, tY, tXY;
     if (mirror) {
         tN = Hn + Ln; tX = Hx - Lx; tXX = Hxx + Lxx; tY = Hy + Ly; tXY = Hxy - Lxy;
@@ -118,22 +93,21 @@ __device__ __forceinline__ hy_abd nm_window(const float *__restrict__ S, const i
 #define NM_ADD4(v) acc += v.x; v.x = acc; acc += v.y; v.y = acc; acc += v.z; v.z = acc; acc += v.w; v.w = acc;
 #define NM_HALF(cur, nxt, kc, kn)                                                   \
     _Pragma("unroll") for (int u = 0; u < 8; u++) {                                 \
-        nxt[u] = *reinterpret_cast<float4 *>(q + (((kn) + 4 * u) ^ xs));            \
+        nxt[u] = *reinterpret_cast<float4 *>(q + (kn) + 4 * u);                     \
         NM_ADD4(cur[u])                                                             \
-        *reinterpret_cast<float4 *>(q + (((kc) + 4 * u) ^ xs)) = cur[u];            \
+        *reinterpret_cast<float4 *>(q + (kc) + 4 * u) = cur[u];                     \
     }                                                                               \
     _Pragma("unroll") for (int u = 0; u < 8; u++) {                                 \
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                          \
         __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                          \
         __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                          \
     }
-// xs: the row's swizzle (0: none)
-__device__ __forceinline__ void nm_scan(float *__restrict__ q, const int n, const int xs)
+__device__ __forceinline__ void nm_scan(float *__restrict__ q, const int n)
 {
     float acc = 0.f;
     float4 ca[8], cb[8];
 #pragma unroll
-    for (int u = 0; u < 8; u++) ca[u] = *reinterpret_cast<float4 *>(q + ((4 * u) ^ xs));
+    for (int u = 0; u < 8; u++) ca[u] = *reinterpret_cast<float4 *>(q + 4 * u);
     for (int k = 0; k < n; k += 64) {
         const int k2 = (k + 64 < n) ? k + 64 : k;
         NM_HALF(ca, cb, k, k + 32)
@@ -196,7 +170,6 @@ __device__ __forceinline__ hy_abd nm_window_ring(const float *__restrict__ S, co
 // one lane: the running sum carried through 64 more addends, in place (q = the chunk's first row)
 __device__ __forceinline__ void nm_scan_chunk(float *__restrict__ q, float &acc)
 {
-    const int xs = 0;
     float4 ca[8], cb[8];
 #pragma unroll
     for (int u = 0; u < 8; u++) ca[u] = *reinterpret_cast<float4 *>(q + 4 * u);
@@ -323,12 +296,12 @@ __device__ __forceinline__ void put_row(float *__restrict__ q, const float *v, c
 }
 
 // ROWS = ceil(n / 256): thread t holds bins t, t + 256, ... of all NB blocks
-template <int NB, int ROWS, bool RING, bool SWZ>
+template <int NB, int ROWS, bool RING>
 __global__ __launch_bounds__(NM_THREADS + (RING ? 64 : 0)) void k_noisemask(vbm_batch b, const int phases)
 {
     extern __shared__ __align__(16) float SU[];      // [NB][5][NS] addends, then running sums (RING: [NB][5][NM_RSTR]); later rows for M7 / M2 / M8
-    // (no static LDS: the unpadded form fills a quarter of the CU's LDS to the byte; what a block needs of its stream is
-    //  wave-uniform and sits in registers of every thread)
+    __shared__ float s_ncl[NB], s_poste[NB];
+    __shared__ int s_col[NB], s_need[NB];
 
     const vbm_setup *s = b.setup;
     const vbm_psy *p = &s->psy[b.block_mode];
@@ -343,8 +316,7 @@ __global__ __launch_bounds__(NM_THREADS + (RING ? 64 : 0)) void k_noisemask(vbm_
     const int nb = VMIN(NB, ncb - lane0);
     const int tid = (int)threadIdx.x;
     const bool scanw = RING && tid >= NM_THREADS;      // the scan wavefront of the ring form
-    const int NSA = SWZ ? n : NS;                      // pitch of the five sum arrays
-    const int BS = RING ? 5 * NM_RSTR : 5 * NSA;       // floats of LDS per block
+    const int BS = RING ? 5 * NM_RSTR : 5 * NS;        // floats of LDS per block
 
     const int i1 = p->hy_i1, i2 = p->hy_i2;
     const int fixed = p->noisewindowfixed;
@@ -381,29 +353,26 @@ __global__ __launch_bounds__(NM_THREADS + (RING ? 64 : 0)) void k_noisemask(vbm_
     // ---- lb_loudnoise_fix (lib/psy.c:5152-5180); the mean over the middle bins is a double-precision chain in bin
     //      order: a block that needs it (the first block after a change between transition and long blocks) has its
     //      logmdct row put into LDS for one lane to walk
-    float s_ncl[NB], s_poste[NB];
-    int s_col[NB], s_need[NB];
-#pragma unroll
-    for (int blk = 0; blk < NB; blk++) {
-        const int lane = lane0 + (blk < nb ? blk : 0);
+    if (!scanw && tid < nb) {
+        const int lane = lane0 + tid;
         const int sb = lane / b.ch, c = lane - sb * b.ch;
         const int sid = b.stream_id[sb];
         const int col = sid * b.ch + c;
-        s_col[blk] = col;
-        s_poste[blk] = b.poste[lane];
+        s_col[tid] = col;
+        s_poste[tid] = b.poste[lane];
         float noise_compand_level = b.st.lowcomp[col];
         const int lW_block_mode = b.st.lW_block_mode[sid];
         int need = 0;
         if (p->m_val < 0.5) noise_compand_level = -1;
         else if (p->normal_thresh > .45) noise_compand_level = -1;
         else if ((b.block_mode == 2 && lW_block_mode == 3) || (b.block_mode == 3 && lW_block_mode == 2)) need = 1;
-        s_ncl[blk] = noise_compand_level;
-        s_need[blk] = (blk < nb) ? need : 0;
+        s_ncl[tid] = noise_compand_level;
+        s_need[tid] = need;
     }
+    __syncthreads();
     {
         int any = 0;
-#pragma unroll
-        for (int blk = 0; blk < NB; blk++) any |= s_need[blk];
+        for (int blk = 0; blk < nb; blk++) any |= s_need[blk];
         if (any) {      // (uniform over the workgroup)
             if (!scanw)
 #pragma unroll
@@ -415,37 +384,25 @@ __global__ __launch_bounds__(NM_THREADS + (RING ? 64 : 0)) void k_noisemask(vbm_
                         if (blk < nb) SU[(size_t)blk * BS + i] = lm[r][blk];
             }
             __syncthreads();
-            if (!scanw && tid < nb) {
-                int need = 0;
-#pragma unroll
-                for (int blk = 0; blk < NB; blk++) if (blk == tid) need = s_need[blk];
-                if (need) {
-                    double hi_th = 0;
-                    const int n25p = p->n25p, n75p = p->n75p;
-                    float *row = SU + (size_t)tid * BS;
-                    for (int k = n25p; k < n75p; k++) {
-                        const float v = row[k];
-                        hi_th += (v > -130) ? (double)v : -130.;
-                    }
-                    hi_th /= n;
-                    float noise_compand_level;
-                    if (hi_th > -40.) noise_compand_level = -1;
-                    else if (hi_th < -50.) noise_compand_level = 1.f;
-                    else noise_compand_level = (float)(1. - ((hi_th + 50) / 10));
-                    row[n] = noise_compand_level;       // (a word behind the row: every thread of the workgroup picks it up)
+            if (!scanw && tid < nb && s_need[tid]) {
+                double hi_th = 0;
+                const int n25p = p->n25p, n75p = p->n75p;
+                const float *row = SU + (size_t)tid * BS;
+                for (int k = n25p; k < n75p; k++) {
+                    const float v = row[k];
+                    hi_th += (v > -130) ? (double)v : -130.;
                 }
+                hi_th /= n;
+                float noise_compand_level;
+                if (hi_th > -40.) noise_compand_level = -1;
+                else if (hi_th < -50.) noise_compand_level = 1.f;
+                else noise_compand_level = (float)(1. - ((hi_th + 50) / 10));
+                s_ncl[tid] = noise_compand_level;
             }
-            __syncthreads();
-#pragma unroll
-            for (int blk = 0; blk < NB; blk++)
-                if (s_need[blk]) s_ncl[blk] = SU[(size_t)blk * BS + n];
             __syncthreads();
         }
     }
-    if (!scanw && tid < nb) {
-#pragma unroll
-        for (int blk = 0; blk < NB; blk++) if (blk == tid) b.st.lowcomp[s_col[blk]] = s_ncl[blk];
-    }
+    if (!scanw && tid < nb) b.st.lowcomp[s_col[tid]] = s_ncl[tid];
 
     // ---- the two passes of bark_noise_hybridmp (lib/psy.c:3799-3812)
     if constexpr (RING) {
@@ -537,10 +494,10 @@ __global__ __launch_bounds__(NM_THREADS + (RING ? 64 : 0)) void k_noisemask(vbm_
             if (i < n)
 #pragma unroll
                 for (int blk = 0; blk < NB; blk++)
-                    if (blk < nb) nm_terms<SWZ>(pass == 1 ? lm[r][blk] : wk[r][blk], i, offset, SU + (size_t)blk * BS, NSA, 5 * blk);
+                    if (blk < nb) nm_terms(pass == 1 ? lm[r][blk] : wk[r][blk], i, offset, SU + (size_t)blk * 5 * NS, NS);
         }
         __syncthreads();
-        if (tid < nb * 5 && (phases & 1)) nm_scan(SU + (size_t)tid * NSA, n, SWZ ? NM_X(tid) : 0);   // lane = 5 blk + sum
+        if (tid < nb * 5 && (phases & 1)) nm_scan(SU + (size_t)tid * NS, n);
         __syncthreads();
         if (phases & 2) {
 #pragma unroll
@@ -557,9 +514,9 @@ __global__ __launch_bounds__(NM_THREADS + (RING ? 64 : 0)) void k_noisemask(vbm_
 #pragma unroll
                 for (int blk = 0; blk < NB; blk++) {
                     if (blk >= nb) continue;
-                    const float *S = SU + (size_t)blk * BS;
+                    const float *S = SU + (size_t)blk * 5 * NS;
                     hy_abd v; v.A = 0.f; v.B = 0.f; v.D = 1.f;
-                    if (have) v = nm_window<SWZ>(S, NSA, wlo[r], whi[r], mirror, 5 * blk);
+                    if (have) v = nm_window(S, NS, wlo[r], whi[r], mirror);
                     float R = (v.A + x * v.B) / v.D;
                     if (R < 0.f) R = 0.f;
                     float nzv = R - offset;
@@ -568,8 +525,8 @@ __global__ __launch_bounds__(NM_THREADS + (RING ? 64 : 0)) void k_noisemask(vbm_
                     } else {
                         if (fixed > 0) {
                             hy_abd w = v;
-                            if (fw >= 0) w = nm_window<SWZ>(S, NSA, flo, fhi, fw < f1, 5 * blk);
-                            else if (i < i2 && have) w = nm_window<SWZ>(S, NSA, p->bark_lo[i2 - 1], p->bark_hi[i2 - 1], i2 - 1 < i1, 5 * blk);
+                            if (fw >= 0) w = nm_window(S, NS, flo, fhi, fw < f1);
+                            else if (i < i2 && have) w = nm_window(S, NS, p->bark_lo[i2 - 1], p->bark_hi[i2 - 1], i2 - 1 < i1);
                             R = (w.A + x * w.B) / w.D;
                             if (R - offset < nzv) nzv = R - offset;
                         }
@@ -682,9 +639,7 @@ __global__ __launch_bounds__(NM_THREADS + (RING ? 64 : 0)) void k_noisemask(vbm_
             float *logmask = SU + (size_t)blk * BS + SK + i + k;
             float np = 0.f;
             if (i < min_nn_lp) {
-                float poste = 0.f;
-#pragma unroll
-                for (int b2 = 0; b2 < NB; b2++) if (b2 == blk) poste = s_poste[b2];
+                const float poste = s_poste[blk];
                 if (poste > 0) {
                     const float temp = VMIN(VMIN(poste, 30.f), noiseoffset1[i] + 30.f);
                     if (!(temp <= 0)) {
@@ -728,18 +683,18 @@ __global__ __launch_bounds__(NM_THREADS + (RING ? 64 : 0)) void k_noisemask(vbm_
     }
 }
 
-template <int NB, int ROWS, bool RING = false, bool SWZ = false>
+template <int NB, int ROWS, bool RING = false>
 int launch(const vbm_batch *b, hipStream_t st)
 {
     // (called from several host threads at once: one-time set-up through initialisers of function-local statics)
     static const int phases = getenv("VBM_NOISE_PHASES") ? atoi(getenv("VBM_NOISE_PHASES")) : 31;   // timing experiments
-    size_t lds = (size_t)5 * NB * (RING ? NM_RSTR : SWZ ? b->n : b->n + NM_PAD) * sizeof(float);
+    size_t lds = (size_t)5 * NB * (RING ? NM_RSTR : b->n + NM_PAD) * sizeof(float);
     if (getenv("VBM_NOISE_LDS_PAD")) lds += (size_t)atoi(getenv("VBM_NOISE_LDS_PAD")) * 1024;   // occupancy experiments
-    static const bool attr = hipFuncSetAttribute(reinterpret_cast<const void *>(k_noisemask<NB, ROWS, RING, SWZ>),
+    static const bool attr = hipFuncSetAttribute(reinterpret_cast<const void *>(k_noisemask<NB, ROWS, RING>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
     (void)attr;
     const unsigned wgs = (unsigned)((b->ncb + NB - 1) / NB);
-    hipLaunchKernelGGL((k_noisemask<NB, ROWS, RING, SWZ>), dim3((wgs + 7u) & ~7u), dim3(NM_THREADS + (RING ? 64 : 0)), lds, st, *b, phases);
+    hipLaunchKernelGGL((k_noisemask<NB, ROWS, RING>), dim3((wgs + 7u) & ~7u), dim3(NM_THREADS + (RING ? 64 : 0)), lds, st, *b, phases);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -751,21 +706,16 @@ extern "C" int vbm_launch_noisemask(const vbm_batch *b, hipStream_t st)
 {
     const int n = b->n;
     if ((n & 63) || n < 128 || n > 4096) return -2;     // (M7's scratch rows live in a block's five sum arrays)
-    // unpadded sums (four workgroups per CU instead of three), VBM_NOISE_SWZ=1: alone 0.68 ms against 0.73 — and the
-    // from-PCM step 4.68-5.0 ms against 4.59-4.62, the per-block step 2.97 against 2.89 (tools/gpu_check.sh): the fourth
-    // workgroup's 40 KB are LDS the kernels running beside this one no longer get.  Opt-in.
-    static const int swz = getenv("VBM_NOISE_SWZ") ? atoi(getenv("VBM_NOISE_SWZ")) : 0;
-    if (swz) {
-        if (n == 256) return launch<8, 1, false, true>(b, st);
-        if (n == 512) return launch<4, 2, false, true>(b, st);
-        if (n == 1024 && !b->noise_ring) return launch<2, 4, false, true>(b, st);
-    }
     if (n <= 256) return launch<8, 1>(b, st);
     if (n <= 512) return launch<4, 2>(b, st);
+    // (occupancy experiments, round 3, tools/gpu_noise_occ.sh / gpu_ab_env.sh — all removed again: the kernel's time alone goes
+    //  with 1 / workgroups per CU: 0.73 ms at three, 0.96 at two, 1.74 at one.  A fourth workgroup per CU — sums without
+    //  padding = exactly a quarter of the LDS, rows XOR-swizzled per sum so that the ten scan lanes still hit ten banks, the
+    //  per-block scalars in registers instead of static LDS — takes 0.68 ms alone and makes the from-PCM step 4.68-5.0 ms
+    //  against 4.59-4.62 (LDS the kernels beside this one no longer get); even the register scalars alone cost the padded
+    //  form 1 %.  One block per workgroup (seven workgroups per CU, 4-byte row stores): 0.90 ms alone.  At most two
+    //  workgroups per CU: from PCM 5.2 ms against 4.7.  Three it is.)
     if (n == 1024 && b->noise_ring) return launch<2, 4, true>(b, st);     // ring form: host-checked window reaches (configure())
-    // (occupancy experiments, round 3, tools/gpu_noise_occ.sh / gpu_ab_env.sh: one block per workgroup — seven workgroups per
-    //  CU, 4-byte row stores — 0.90 ms alone; at most two workgroups per CU 0.96 ms alone and the from-PCM step 5.2 ms
-    //  against 4.7; four, see above.  Three it is.)
     if (n <= 1024) return launch<2, 4>(b, st);
     return launch<1, 16>(b, st);
 }
