@@ -1045,7 +1045,11 @@ extern "C" int vbm_launch_floor_fit(const vbm_batch *b, hipStream_t st)
     // from PCM 4.80 against 4.94), and the cooperative one serves the small batches, whose chain of kernels is what a
     // stream inside a run of short blocks waits for.  VBM_FLOORFIT_COOP: 0 never, 1 small batches (default), 2 always.
     static const int coop = getenv("VBM_FLOORFIT_COOP") ? atoi(getenv("VBM_FLOORFIT_COOP")) : 1;
-    if (coop == 2 || (coop == 1 && (b->few || b->ncb <= 64 * 64))) {
+    // "Small": up to 8192 channel-blocks (VBM_FLOORFIT_COOP_MAX) — the rounds of a 4096-stream pool of the drop-in shim are
+    // that size: 27.3-27.9 k streams at 1x through the reference's entry points against 25.2-25.7 k with the limit at 4096;
+    // the from-PCM step of the batched boundary does not notice (its small batches carry the `few` flag anyway).
+    static const int coop_max = getenv("VBM_FLOORFIT_COOP_MAX") ? atoi(getenv("VBM_FLOORFIT_COOP_MAX")) : 128 * 64;
+    if (coop == 2 || (coop == 1 && (b->few || b->ncb <= coop_max))) {
         const int pmax = b->fit_max_posts;
         const size_t lds = (size_t)4 * (((pmax - 1) * 10 + ((10 * pmax + 1) >> 1) + 1) & ~1) * sizeof(int);
         static const int phases = getenv("VBM_FLOORFIT_PHASES") ? atoi(getenv("VBM_FLOORFIT_PHASES")) : 31;   // timing experiments
