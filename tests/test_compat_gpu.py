@@ -132,6 +132,11 @@ def test_many_streams_through_the_reference_api(oracle, cuda, dll, defer, device
     nblocks = sum(len(g) for g in got)
     # one batched round per block generation, not one per block
     assert used < nblocks / 4, (used, nblocks)
+    # where the host's time went (VORBIS_MI355X_TIMES): rounds were run, and the writes of this test (1024 samples, one
+    # vorbis_analysis_wrote per vorbis_analysis_buffer) went through the pinned arena, not through staging copies
+    times = (C.c_double * 8)()
+    assert dll.vorbis_mi355x_ctl(6, times) == 0
+    assert times[3] > 0 and all(t >= 0 for t in times)
     for st in ss:
         st.close()
 
