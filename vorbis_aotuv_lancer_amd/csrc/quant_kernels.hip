@@ -27,45 +27,29 @@
 
 namespace {
 
+// Per bin of one partition (start bin i, jn bins): res = mdct / floor and the coupling class of the bin — 1 lossless,
+// -1 lossy only if the partner agrees, 0 lossy (what lib/psy.c:4584-4624 decides).  Two magnitude limits apply: below
+// the setup's point limit the pre-point pair, above it the post-point pair; the one partition that straddles the limit
+// ramps from one pair to the other in jn equal steps.  The ramp is a RUNNING float sum in the source (its rounding is
+// part of the result), so it is kept as one here.  The first limit is lowered by the bin's tone peak, never below the
+// pre-point value.
 __device__ __forceinline__ void flag_lossless(int limit, float prepoint, float postpoint, float prepoint_r, float postpoint_r,
                               float *res, const float *mdct, const float *enpeak, const float *floor, int *flag,
                               int i, int jn)
 {
-    int j, ps = 0;
-    int pointlimit = limit - i;
-    float point1, point2, bakp1, r;
-    float ps1 = 0.f, ps2 = 0.f;
-
-    if (pointlimit > 0) {
-        point1 = prepoint;
-        point2 = prepoint_r;
-        if ((pointlimit - jn) <= 0) {
-            ps1 = (postpoint - prepoint) / jn;
-            ps2 = (postpoint_r - prepoint_r) / jn;
-            ps = 1;
-        }
-    } else {
-        point1 = postpoint;
-        point2 = postpoint_r;
-    }
-    for (j = 0; j < jn; j++) {
-        if (ps == 1) {
-            point1 += ps1;
-            point2 += ps2;
-        }
-        bakp1 = point1;
-
-        res[j] = mdct[j] / floor[j];
-        r = fabsf(res[j]);
-        point1 -= enpeak[j];
-        if (point1 < prepoint) point1 = prepoint;
-        if (r < point1) {
-            if (r < point2) flag[j] = 0;
-            else flag[j] = -1;
-        } else {
-            flag[j] = 1;
-        }
-        point1 = bakp1;
+    const int room = limit - i;                         // bins from the partition's start up to the point limit
+    const bool below = room > 0, ramp = below && room <= jn;
+    float lim1 = below ? prepoint : postpoint, lim2 = below ? prepoint_r : postpoint_r;
+    const float step1 = ramp ? (postpoint - prepoint) / jn : 0.f, step2 = ramp ? (postpoint_r - prepoint_r) / jn : 0.f;
+    for (int j = 0; j < jn; j++) {
+        if (ramp) { lim1 += step1; lim2 += step2; }
+        const float q = mdct[j] / floor[j];
+        res[j] = q;
+        const float mag = fabsf(q);
+        float lowered = lim1 - enpeak[j];
+        if (lowered < prepoint) lowered = prepoint;
+        // (comparisons as the source orders them: an unordered magnitude counts as lossless)
+        flag[j] = !(mag < lowered) ? 1 : (mag < lim2 ? 0 : -1);
     }
 }
 
