@@ -90,3 +90,14 @@ def test_managed_min_max_from_pcm_with_silence(oracle, cuda):
 ])
 def test_managed_other_classes_from_pcm(oracle, cuda, ch, rate, bitrate, secs):
     frontend_vs_oracle(oracle, cuda, ch, rate, None, NS=4, seconds=secs, bitrate=bitrate)
+
+
+# Other managed-bitrate classes (vorbis_encode_init): mono (the lane-per-bin couple kernel without coupling walks the
+# blobs), 22.05 kHz (512 / 1024 blocks), coupled 5.1 (the general couple kernel: one launch per blob between the wide
+# launches), and the stereo 44.1 / 48 kHz bitrate ladder.  Oracle-only pin (the reference's dumps are VBR).
+@pytest.mark.parametrize("ch,rate,bitrate", [
+    (1, 44100, 64000), (2, 22050, 56000), (6, 48000, 320000),
+    (2, 44100, 64000), (2, 44100, 96000), (2, 44100, 160000), (2, 44100, 192000), (2, 44100, 256000), (2, 48000, 128000),
+])
+def test_other_managed_classes_from_pcm(oracle, cuda, ch, rate, bitrate):
+    frontend_vs_oracle(oracle, cuda, ch, rate, None, NS=4, seconds=1.7, bitrate=bitrate)

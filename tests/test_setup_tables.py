@@ -21,7 +21,7 @@ def fetch(fn, handle, name):
     return np.frombuffer(buf, dtype=dt).copy()
 
 
-@pytest.mark.parametrize("ch,rate,q", [(2, 44100, 0.5), (6, 48000, 0.8), (2, 44100, 0.1)])
+@pytest.mark.parametrize("ch,rate,q", [(2, 44100, 0.5), (6, 48000, 0.8), (2, 44100, 0.1), (2, 48000, 0.8), (1, 44100, 0.2)])
 def test_host_setup_tables_match_oracle(oracle, ch, rate, q):
     import vorbis_aotuv_lancer_amd as v
     o = orc.Setup(oracle, ch, rate, q)
