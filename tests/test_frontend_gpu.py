@@ -248,6 +248,9 @@ def test_frontend_output_does_not_depend_on_round_policy(oracle, cuda):
     (8, 44100, 0.5),
     (8, 48000, 0.5),     # ve_setup_48_uncoupled
     (2, 96000, 0.5),     # ve_setup_X_stereo (lib/modes/setup_X.h, lib/vorbisenc.c:185-188)
+    # the quality ladder (round 3, late): interpolated settings between the table rows of the templates
+    (2, 44100, 0.7), (2, 48000, 0.2), (2, 48000, 0.9), (1, 44100, 0.2), (1, 44100, 0.9), (2, 32000, 0.2), (2, 22050, 0.8),
+    (6, 48000, 0.5), (6, 44100, 0.5), (6, 48000, 0.1),
 ])
 def test_frontend_other_mode_classes_match_oracle(oracle, cuda, ch, rate, q):
     # the 11 kHz and 8 kHz setups have a single block size: only block types 0 and 1 exist
