@@ -249,6 +249,46 @@ int vbm_mapping0_forward(vorbis_block *vb);
 extern const vorbis_func_mapping mapping0_exportbundle_mi355x;   /* forward = vbm_mapping0_forward; the header / decode members are NULL */
 
 /* ---- include/vorbis/vorbisenc.h:59, :157 ---------------------------------------------------------- */
+/* The three-step form of the same setup (reference include/vorbis/vorbisenc.h:96-219, lib/vorbisenc.c:977-1260), as
+ * oggenc-style programs use it: vorbis_encode_setup_vbr / _managed choose the mode pack, vorbis_encode_ctl may look at it,
+ * vorbis_encode_setup_init seals it (a vorbis_info whose setup is not sealed is refused by vorbis_analysis_init).  The
+ * setup is a SHIPPED pack, so vorbis_encode_ctl answers the read requests from it and accepts only those changes that
+ * change nothing:
+ *   OV_ECTL_RATEMANAGE2_GET  filled from the pack (reservoir, bias, damping as vorbis_encode_setup_managed leaves them)
+ *   OV_ECTL_RATEMANAGE2_SET  NULL on a VBR setup (what oggenc -q does: "no management"): 0; the values the setup already
+ *                            has: 0; anything else OV_EIMPL
+ *   OV_ECTL_LOWPASS_GET / _IBLOCK_GET / _COUPLING_GET   the pack's lowpass (kHz), 0., 1
+ *   OV_ECTL_LOWPASS_SET / _IBLOCK_SET / _COUPLING_SET   the value the setup already has: 0; anything else OV_EIMPL
+ *   the deprecated OV_ECTL_RATEMANAGE_* requests       OV_EIMPL
+ * and, like the reference, refuses every change after vorbis_encode_setup_init with OV_EINVAL. */
+struct ovectl_ratemanage2_arg {
+    int management_active;
+    long bitrate_limit_min_kbps;
+    long bitrate_limit_max_kbps;
+    long bitrate_limit_reservoir_bits;
+    double bitrate_limit_reservoir_bias;
+    long bitrate_average_kbps;
+    double bitrate_average_damping;
+};
+#define OV_ECTL_RATEMANAGE_GET   0x10
+#define OV_ECTL_RATEMANAGE_SET   0x11
+#define OV_ECTL_RATEMANAGE_AVG   0x12
+#define OV_ECTL_RATEMANAGE_HARD  0x13
+#define OV_ECTL_RATEMANAGE2_GET  0x14
+#define OV_ECTL_RATEMANAGE2_SET  0x15
+#define OV_ECTL_LOWPASS_GET      0x20
+#define OV_ECTL_LOWPASS_SET      0x21
+#define OV_ECTL_IBLOCK_GET       0x30
+#define OV_ECTL_IBLOCK_SET       0x31
+#define OV_ECTL_COUPLING_GET     0x40
+#define OV_ECTL_COUPLING_SET     0x41
+int vorbis_encode_setup_vbr(vorbis_info *vi, long channels, long rate, float quality);
+int vorbis_encode_setup_managed(vorbis_info *vi, long channels, long rate, long max_bitrate, long nominal_bitrate,
+                                long min_bitrate);
+int vorbis_encode_setup_init(vorbis_info *vi);
+int vorbis_encode_ctl(vorbis_info *vi, int number, void *arg);
+/* the comment header alone; op->packet is malloc'ed and belongs to the caller (lib/info.c:600-617) */
+int vorbis_commentheader_out(vorbis_comment *vc, ogg_packet *op);
 int vorbis_encode_init_vbr(vorbis_info *vi, long channels, long rate, float base_quality);
 int vorbis_encode_init(vorbis_info *vi, long channels, long rate, long max_bitrate, long nominal_bitrate,
                        long min_bitrate);

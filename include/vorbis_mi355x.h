@@ -349,6 +349,8 @@ int vbm_frontend_device_stats(vbm_frontend *fe, unsigned long long *out);
  * examples/encoder_example.c:150-157). */
 int vbm_header_packets(const vbm_setup_handle *setup, const char *vendor, const char *const *comments,
                        int ncomments, uint8_t *buf, long cap, long *lens);
+/* The comment header alone (reference vorbis_commentheader_out, lib/info.c:600-617); buf == NULL: size query. */
+int vbm_comment_packet(const char *vendor, const char *const *comments, int ncomments, uint8_t *buf, long cap, long *len);
 typedef struct vbm_ogg_stream vbm_ogg_stream;
 int vbm_ogg_stream_create(vbm_ogg_stream **os, int serialno);
 void vbm_ogg_stream_destroy(vbm_ogg_stream *os);

@@ -46,6 +46,13 @@ class VorbisComment(C.Structure):
                 ("comments", C.c_int), ("vendor", C.c_char_p)]
 
 
+class RateManage2(C.Structure):
+    """struct ovectl_ratemanage2_arg (include/vorbis/vorbisenc.h)"""
+    _fields_ = [("management_active", C.c_int), ("bitrate_limit_min_kbps", C.c_long), ("bitrate_limit_max_kbps", C.c_long),
+                ("bitrate_limit_reservoir_bits", C.c_long), ("bitrate_limit_reservoir_bias", C.c_double),
+                ("bitrate_average_kbps", C.c_long), ("bitrate_average_damping", C.c_double)]
+
+
 def bind(dll):
     """argtypes / restypes of the entry points the tests call"""
     P = C.POINTER
@@ -79,6 +86,11 @@ def bind(dll):
     dll.vorbis_bitrate_addblock.argtypes = [P(VorbisBlock)]
     dll.vorbis_bitrate_flushpacket.argtypes = [P(VorbisDspState), P(OggPacket)]
     dll.vorbis_mi355x_ctl.argtypes = [C.c_int, C.c_void_p]
+    dll.vorbis_encode_setup_vbr.argtypes = [P(VorbisInfo), C.c_long, C.c_long, C.c_float]
+    dll.vorbis_encode_setup_managed.argtypes = [P(VorbisInfo), C.c_long, C.c_long, C.c_long, C.c_long, C.c_long]
+    dll.vorbis_encode_setup_init.argtypes = [P(VorbisInfo)]
+    dll.vorbis_encode_ctl.argtypes = [P(VorbisInfo), C.c_int, C.c_void_p]
+    dll.vorbis_commentheader_out.argtypes = [P(VorbisComment), P(OggPacket)]
     return dll
 
 
@@ -86,16 +98,21 @@ class Stream:
     """One reference-API encoder stream: vorbis_info + vorbis_dsp_state + vorbis_block, driven like
     examples/encoder_example.c drives them."""
 
-    def __init__(self, dll, ch, rate, q=None, bitrate=None):
+    def __init__(self, dll, ch, rate, q=None, bitrate=None, three_step=False):
+        """three_step: vorbis_encode_setup_vbr / _managed + vorbis_encode_ctl + vorbis_encode_setup_init, as oggenc does"""
         self.dll, self.ch = dll, ch
         self.vi, self.vd, self.vb = VorbisInfo(), VorbisDspState(), VorbisBlock()
         dll.vorbis_info_init(self.vi)
         if bitrate is None:
-            rc = dll.vorbis_encode_init_vbr(self.vi, ch, rate, q)
+            rc = (dll.vorbis_encode_setup_vbr if three_step else dll.vorbis_encode_init_vbr)(self.vi, ch, rate, q)
         else:
             mx, nom, mn = bitrate if isinstance(bitrate, (tuple, list)) else (-1, bitrate, -1)
-            rc = dll.vorbis_encode_init(self.vi, ch, rate, mx, nom, mn)
+            rc = (dll.vorbis_encode_setup_managed if three_step else dll.vorbis_encode_init)(self.vi, ch, rate, mx, nom, mn)
         assert rc == 0, rc
+        if three_step:
+            if bitrate is None:
+                assert dll.vorbis_encode_ctl(self.vi, 0x15, None) == 0       # OV_ECTL_RATEMANAGE2_SET, NULL: no management
+            assert dll.vorbis_encode_setup_init(self.vi) == 0
         assert dll.vorbis_analysis_init(self.vd, self.vi) == 0
         assert dll.vorbis_block_init(self.vd, self.vb) == 0
 

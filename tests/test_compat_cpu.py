@@ -113,3 +113,71 @@ def test_no_cpu_path_behind_the_entry_points(dll):
     assert dll.vorbis_analysis(vb, None) == compat.OV_EINVAL
     assert dll.vorbis_bitrate_flushpacket(vd, op) == 0
     dll.vorbis_info_clear(vi)
+
+
+def test_three_step_setup_and_ctl(dll):
+    """vorbis_encode_setup_vbr / _managed + vorbis_encode_ctl + vorbis_encode_setup_init (reference lib/vorbisenc.c:977-1260):
+    read requests answered from the mode pack, changes accepted only where they change nothing, everything refused once
+    the setup is sealed; an unsealed vorbis_info is not accepted by vorbis_analysis_init."""
+    GET2, SET2, LP_GET, LP_SET, IB_GET, IB_SET, CP_GET, CP_SET = 0x14, 0x15, 0x20, 0x21, 0x30, 0x31, 0x40, 0x41
+    vi = compat.VorbisInfo()
+    dll.vorbis_info_init(vi)
+    assert dll.vorbis_encode_setup_vbr(vi, 2, 44100, 0.5) == 0
+    rm = compat.RateManage2()
+    assert dll.vorbis_encode_ctl(vi, GET2, C.byref(rm)) == 0 and rm.management_active == 0
+    assert dll.vorbis_encode_ctl(vi, SET2, None) == 0                     # oggenc -q: "no rate management" — already so
+    lp = C.c_double()
+    assert dll.vorbis_encode_ctl(vi, LP_GET, C.byref(lp)) == 0 and abs(lp.value - 19.5) < 1e-3      # SURVEY 8: 19.500027 kHz
+    assert dll.vorbis_encode_ctl(vi, LP_SET, C.byref(lp)) == 0
+    assert dll.vorbis_encode_ctl(vi, LP_SET, C.byref(C.c_double(15.0))) == compat.OV_EIMPL          # a different setup: not shipped
+    ib, cp = C.c_double(-1), C.c_int(-1)
+    assert dll.vorbis_encode_ctl(vi, IB_GET, C.byref(ib)) == 0 and ib.value == 0.0
+    assert dll.vorbis_encode_ctl(vi, CP_GET, C.byref(cp)) == 0 and cp.value == 1
+    assert dll.vorbis_encode_ctl(vi, IB_SET, C.byref(C.c_double(-5.0))) == compat.OV_EIMPL
+    assert dll.vorbis_encode_ctl(vi, CP_SET, C.byref(C.c_int(1))) == 0
+    assert dll.vorbis_encode_ctl(vi, 0x10, C.byref(rm)) == compat.OV_EIMPL                          # deprecated interface
+    vd = compat.VorbisDspState()
+    assert dll.vorbis_analysis_init(vd, vi) == 1                          # not sealed yet
+    assert dll.vorbis_encode_setup_init(vi) == 0
+    assert dll.vorbis_encode_ctl(vi, SET2, None) == compat.OV_EINVAL      # set in stone (lib/vorbisenc.c:1078)
+    assert dll.vorbis_encode_ctl(vi, LP_GET, C.byref(lp)) == 0            # reading stays possible
+    dll.vorbis_info_clear(vi)
+
+    dll.vorbis_info_init(vi)
+    assert dll.vorbis_encode_setup_managed(vi, 2, 44100, 144000, 128000, 112000) == 0
+    assert dll.vorbis_encode_ctl(vi, GET2, C.byref(rm)) == 0
+    assert (rm.management_active, rm.bitrate_limit_min_kbps, rm.bitrate_limit_max_kbps, rm.bitrate_average_kbps) == (1, 112, 144, 128)
+    assert rm.bitrate_limit_reservoir_bits == 256000 and abs(rm.bitrate_limit_reservoir_bias - 0.1) < 1e-12
+    assert abs(rm.bitrate_average_damping - 1.5) < 1e-6                   # lib/vorbisenc.c:1040-1043
+    assert dll.vorbis_encode_ctl(vi, SET2, C.byref(rm)) == 0              # the values it has
+    rm.bitrate_average_kbps = 96
+    assert dll.vorbis_encode_ctl(vi, SET2, C.byref(rm)) == compat.OV_EIMPL
+    assert dll.vorbis_encode_ctl(vi, SET2, None) == compat.OV_EIMPL       # would turn a managed pack into a VBR one
+    assert dll.vorbis_encode_setup_init(vi) == 0
+    dll.vorbis_info_clear(vi)
+    assert dll.vorbis_encode_setup_vbr(vi, 2, 0, 0.5) == compat.OV_EINVAL
+
+
+def test_commentheader_out(dll):
+    """the comment header alone (lib/info.c:600-617): 0x03 "vorbis", vendor, the comments, the framing bit; the same bytes
+    as the second packet of the three headers"""
+    import vorbis_aotuv_lancer_amd as v
+    vc = compat.VorbisComment()
+    dll.vorbis_comment_init(vc)
+    dll.vorbis_comment_add_tag(vc, b"ARTIST", b"somebody")
+    dll.vorbis_comment_add_tag(vc, b"TITLE", b"something")
+    op = compat.OggPacket()
+    assert dll.vorbis_commentheader_out(vc, op) == 0
+    pkt = bytes(op.packet[:op.bytes])
+    assert pkt[:7] == b"\x03vorbis" and pkt[-1] == 1 and op.packetno == 1 and op.b_o_s == 0
+    vlen = int.from_bytes(pkt[7:11], "little")
+    at = 11 + vlen
+    assert int.from_bytes(pkt[at:at + 4], "little") == 2
+    at += 4
+    for want in (b"ARTIST=somebody", b"TITLE=something"):
+        n = int.from_bytes(pkt[at:at + 4], "little")
+        assert pkt[at + 4:at + 4 + n] == want
+        at += 4 + n
+    assert at == len(pkt) - 1
+    C.CDLL(None).free(op.packet)                                         # the packet belongs to the caller
+    dll.vorbis_comment_clear(vc)

@@ -176,6 +176,24 @@ def test_entry_point_bookkeeping(oracle, cuda, dll):
     sm.close()
 
 
+@pytest.mark.parametrize("bitrate", [None, 128000])
+def test_three_step_setup_encodes_the_same(oracle, cuda, dll, bitrate):
+    """a stream set up the way oggenc does it (vorbis_encode_setup_vbr / _managed, vorbis_encode_ctl,
+    vorbis_encode_setup_init) against the oracle"""
+    ch, rate, q = 2, 44100, (0.5 if bitrate is None else None)
+    sig = synth_signal(ch, rate, 12 * 1024, seed=31)
+    want = oracle_streams(oracle, ch, rate, q, [sig], bitrate=bitrate)[0]
+    st = compat.Stream(dll, ch, rate, q, bitrate=bitrate, three_step=True)
+    got = []
+    for at in range(0, sig.shape[1], 1024):
+        assert st.write(sig[:, at:at + 1024]) == 0
+        got.extend(st.drain())
+    assert st.finish() == 0
+    got.extend(st.drain())
+    st.close()
+    assert [g[1] for g in got] == [w[1] for w in want] and [g[0] for g in got] == [w[0] for w in want]
+
+
 def test_managed_streams_and_slot_reuse(oracle, cuda, dll):
     """vorbis_encode_init classes through the same calls; a finished stream's slot serves the next stream"""
     ch, rate, NS = 2, 44100, 3

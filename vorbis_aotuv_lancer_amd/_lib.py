@@ -71,6 +71,7 @@ SIGNATURES = {
     "vbm_frontend_write": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vbm_frontend_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vbm_frontend_write_streams": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "vbm_comment_packet": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_void_p, C.c_long, C.c_void_p]),
     "vbm_frontend_round_types": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "vbm_frontend_write_streams_strided": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_long, C.c_long,
                                                      C.c_int, C.c_void_p]),

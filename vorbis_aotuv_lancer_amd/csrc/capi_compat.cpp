@@ -20,6 +20,7 @@
 #include <chrono>
 #include <deque>
 #include <map>
+#include <set>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -108,6 +109,9 @@ struct cclass {                      // vi->codec_setup; one per mode pack, shar
     std::string leaf;
     int refs = 0;
     long bitrate[3] = {0, 0, 0};     // nominal, lower, upper
+    long reservoir_bits = 0;         // bitrate_manager_info (managed setups)
+    double reservoir_bias = 0., damping = 0.;
+    double lowpass_khz = 0.;         // hi.lowpass_kHz of the setup
     vbm_setup_handle *setup = nullptr;
     int ch = 0, managed = 0, bs[2] = {0, 0};
     long rate = 0;
@@ -121,6 +125,7 @@ int g_carve_ahead = 1;
 int g_defer_blocks = -1;             // -1: environment VORBIS_MI355X_DEFER_BLOCKS, default 0
 std::string g_data_dir;
 long long g_rounds = 0;
+std::set<const vorbis_info *> g_unsealed;   // vorbis_encode_setup_vbr / _managed called, vorbis_encode_setup_init not yet
 // where the host's time goes (VORBIS_MI355X_TIMES): seconds summed over all threads —
 // 0 vorbis_analysis_wrote's copy, 1 staging copies of an upload, 2 upload: H2D + append kernels + waits, 3 the device
 // round (decisions read back, kernels enqueued), 4 packet compaction + D2H waits, 5 filing packets per stream
@@ -464,11 +469,16 @@ int class_open(vorbis_info *vi, long channels, long rate, const std::string &lea
         c->rate = rate;
         c->bs[0] = inf[2];
         c->bs[1] = inf[3];
-        if (vbm_setup_table(h, "bitrate", &data, &count, &kind) == 0 && kind == 'd' && count >= 4) {
-            const double *bi = (const double *)data;   // managed, nominal, lower, upper
+        if (vbm_setup_table(h, "bitrate", &data, &count, &kind) == 0 && kind == 'd' && count >= 7) {
+            const double *bi = (const double *)data;   // managed, nominal, lower, upper, reservoir bits, bias, damping
             c->managed = bi[0] != 0.;
             for (int k = 0; k < 3; k++) c->bitrate[k] = (long)bi[1 + k];
+            c->reservoir_bits = (long)bi[4];
+            c->reservoir_bias = bi[5];
+            c->damping = bi[6];
         }
+        if (vbm_setup_table(h, "lowpass_kHz", &data, &count, &kind) == 0 && kind == 'd' && count >= 1)
+            c->lowpass_khz = ((const double *)data)[0];
         g_classes[mode] = c;
     }
     c->refs++;
@@ -515,6 +525,10 @@ extern "C" void vorbis_info_clear(vorbis_info *vi)
 {
     if (!vi) return;
     cclass *c = (cclass *)vi->codec_setup;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        g_unsealed.erase(vi);
+    }
     if (c) {
         std::lock_guard<std::mutex> lk(g_mu);
         if (--c->refs <= 0) {                        // the last vorbis_info of the class: pools and tables go
@@ -620,10 +634,123 @@ extern "C" int vorbis_encode_init(vorbis_info *vi, long channels, long rate, lon
     return class_open(vi, channels, rate, leaf + ".vpk");
 }
 
+// ---- the three-step setup (reference lib/vorbisenc.c:977-1260) ------------------------------------------------
+extern "C" int vorbis_encode_setup_vbr(vorbis_info *vi, long channels, long rate, float quality)
+{
+    if (rate <= 0) return OV_EINVAL;
+    int rc = vorbis_encode_init_vbr(vi, channels, rate, quality);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_unsealed.insert(vi);
+    return 0;
+}
+
+extern "C" int vorbis_encode_setup_managed(vorbis_info *vi, long channels, long rate, long max_bitrate, long nominal_bitrate,
+                                           long min_bitrate)
+{
+    if (rate <= 0) return OV_EINVAL;
+    int rc = vorbis_encode_init(vi, channels, rate, max_bitrate, nominal_bitrate, min_bitrate);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_unsealed.insert(vi);
+    return 0;
+}
+
+extern "C" int vorbis_encode_setup_init(vorbis_info *vi)
+{
+    if (!vi || !vi->codec_setup) return OV_EINVAL;
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_unsealed.erase(vi);        // (sealing twice is harmless, as in the reference: set_in_stone stays set)
+    return 0;
+}
+
+extern "C" int vorbis_encode_ctl(vorbis_info *vi, int number, void *arg)
+{
+    if (!vi || !vi->codec_setup) return OV_EINVAL;
+    const cclass *c = (const cclass *)vi->codec_setup;
+    const bool set = (number & 0xf) != 0;                 // a read request has a low nibble of 0 (lib/vorbisenc.c:1076)
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (set && !g_unsealed.count(vi)) return OV_EINVAL;   // set_in_stone (:1078)
+    }
+    const long kmin = c->bitrate[1] > 0 ? c->bitrate[1] / 1000 : 0, kmax = c->bitrate[2] > 0 ? c->bitrate[2] / 1000 : 0;
+    switch (number) {
+    case OV_ECTL_RATEMANAGE2_GET: {
+        ovectl_ratemanage2_arg *ai = (ovectl_ratemanage2_arg *)arg;
+        if (!ai) return OV_EINVAL;
+        ai->management_active = c->managed;
+        ai->bitrate_limit_min_kbps = kmin;
+        ai->bitrate_limit_max_kbps = kmax;
+        ai->bitrate_average_kbps = c->bitrate[0] / 1000;
+        ai->bitrate_average_damping = c->damping;
+        ai->bitrate_limit_reservoir_bits = c->reservoir_bits;
+        ai->bitrate_limit_reservoir_bias = c->reservoir_bias;
+        return 0;
+    }
+    case OV_ECTL_RATEMANAGE2_SET: {
+        const ovectl_ratemanage2_arg *ai = (const ovectl_ratemanage2_arg *)arg;
+        if (!ai) return c->managed ? OV_EIMPL : 0;       // "no management": what a VBR pack is already
+        if (!!ai->management_active != !!c->managed) return OV_EIMPL;
+        if (!c->managed) return 0;
+        const bool same = ai->bitrate_limit_min_kbps == kmin && ai->bitrate_limit_max_kbps == kmax &&
+                          ai->bitrate_average_kbps == c->bitrate[0] / 1000 && ai->bitrate_average_damping == c->damping &&
+                          ai->bitrate_limit_reservoir_bits == c->reservoir_bits &&
+                          ai->bitrate_limit_reservoir_bias == c->reservoir_bias;
+        return same ? 0 : OV_EIMPL;
+    }
+    case OV_ECTL_LOWPASS_GET:
+        if (!arg) return OV_EINVAL;
+        *(double *)arg = c->lowpass_khz;
+        return 0;
+    case OV_ECTL_LOWPASS_SET:
+        if (!arg) return OV_EINVAL;
+        return *(const double *)arg == c->lowpass_khz ? 0 : OV_EIMPL;
+    case OV_ECTL_IBLOCK_GET:
+        if (!arg) return OV_EINVAL;
+        *(double *)arg = 0.;                              // hi.impulse_noisetune of a fresh setup
+        return 0;
+    case OV_ECTL_IBLOCK_SET:
+        if (!arg) return OV_EINVAL;
+        return *(const double *)arg == 0. ? 0 : OV_EIMPL;
+    case OV_ECTL_COUPLING_GET:
+        if (!arg) return OV_EINVAL;
+        *(int *)arg = 1;                                  // hi.coupling_p
+        return 0;
+    case OV_ECTL_COUPLING_SET:
+        if (!arg) return OV_EINVAL;
+        return *(const int *)arg ? 0 : OV_EIMPL;
+    }
+    return OV_EIMPL;
+}
+
+extern "C" int vorbis_commentheader_out(vorbis_comment *vc, ogg_packet *op)
+{
+    if (!op) return OV_EFAULT;
+    const int nc = vc ? vc->comments : 0;
+    const char *const *cm = vc ? (const char *const *)vc->user_comments : nullptr;
+    long len = 0;
+    if (vbm_comment_packet(nullptr, cm, nc, nullptr, 0, &len)) return OV_EIMPL;
+    unsigned char *buf = (unsigned char *)malloc((size_t)len);
+    if (!buf) return OV_EFAULT;
+    if (vbm_comment_packet(nullptr, cm, nc, buf, len, &len)) { free(buf); return OV_EIMPL; }
+    memset(op, 0, sizeof(*op));
+    op->packet = buf;
+    op->bytes = len;
+    op->b_o_s = 0;
+    op->e_o_s = 0;
+    op->granulepos = 0;
+    op->packetno = 1;
+    return 0;
+}
+
 // ---- stream life cycle (reference lib/block.c:84-107, :306-409) ----------------------------------------
 extern "C" int vorbis_analysis_init(vorbis_dsp_state *v, vorbis_info *vi)
 {
     if (!v || !vi || !vi->codec_setup) return 1;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (g_unsealed.count(vi)) return 1;      // vorbis_encode_setup_init has not been called
+    }
     cclass *c = (cclass *)vi->codec_setup;
     memset(v, 0, sizeof(*v));
     std::lock_guard<std::mutex> lk(c->mu);

@@ -107,10 +107,16 @@ extern "C" int vbm_setup_table(const vbm_setup_handle *h, const char *name, cons
         memcpy(sc, v, sizeof(sc));
         RET(sc, 12, 'i');
     }
-    if (!strcmp(name, "bitrate")) {   // managed flag + bitrate_manager_info's rates (nominal, lower, upper)
-        static thread_local double sc[4];
+    if (!strcmp(name, "bitrate")) {   // managed flag + bitrate_manager_info: rates (nominal, lower, upper), reservoir, bias, damping
+        static thread_local double sc[7];
         sc[0] = s->managed; sc[1] = (double)s->bi_avg_rate; sc[2] = (double)s->bi_min_rate; sc[3] = (double)s->bi_max_rate;
-        RET(sc, 4, 'd');
+        sc[4] = (double)s->bi_reservoir_bits; sc[5] = s->bi_reservoir_bias; sc[6] = s->bi_slew_damp;
+        RET(sc, 7, 'd');
+    }
+    if (!strcmp(name, "lowpass_kHz")) {
+        static thread_local double lp[1];
+        lp[0] = s->hi_lowpass_khz;
+        RET(lp, 1, 'd');
     }
 #undef RET
     g_vbm_err = std::string("unknown setup table: ") + name;

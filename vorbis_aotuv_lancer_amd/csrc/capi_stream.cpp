@@ -369,6 +369,20 @@ extern "C" int vbm_header_packets(const vbm_setup_handle *setup, const char *ven
     }
 }
 
+// the comment header alone (reference vorbis_commentheader_out, lib/info.c:600-617): size query with buf == NULL
+extern "C" int vbm_comment_packet(const char *vendor, const char *const *comments, int ncomments, uint8_t *buf, long cap,
+                                  long *len)
+{
+    if (!len || ncomments < 0 || (ncomments && !comments)) return VBM_EINVAL;
+    if (!vendor) vendor = "AO; aoTuV [20110424] (based on libvorbis 1.3.7)";
+    const std::vector<uint8_t> p1 = pack_comment(vendor, comments, ncomments);
+    *len = (long)p1.size();
+    if (!buf) return VBM_OK;
+    if (cap < *len) return VBM_EINVAL;
+    memcpy(buf, p1.data(), p1.size());
+    return VBM_OK;
+}
+
 // ---- Ogg pages (doc/framing.html) -----------------------------------------------------------------
 struct vbm_ogg_stream {
     int serialno;

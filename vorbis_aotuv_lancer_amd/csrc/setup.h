@@ -148,6 +148,7 @@ struct vbm_setup {
     int managed;
     long long bi_avg_rate, bi_min_rate, bi_max_rate, bi_reservoir_bits;
     double bi_reservoir_bias, bi_slew_damp;
+    double hi_lowpass_khz;           // highlevel_encode_setup.lowpass_kHz (what OV_ECTL_LOWPASS_GET reports)
     // static tables
     double stereo_threshholds[9], stereo_threshholds_X[9];
     int stn_compand[VBM_NOISE_COMPAND_LEVELS];

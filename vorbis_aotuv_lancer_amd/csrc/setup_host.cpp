@@ -645,6 +645,7 @@ vbm_setup_host *vbm_setup_host_load(const char *common_path, const char *mode_pa
             memcpy(s.sliding_lowpass, mode.i32("psy_g/sliding_lowpass"), sizeof(s.sliding_lowpass));
             s.ampmax_att_per_sec = mode.f32("psy_g/floats")[2];
             s.managed = mode.has("info/managed") ? *mode.i32("info/managed") : 0;
+            s.hi_lowpass_khz = *mode.f64("hi/lowpass_kHz");
             if (s.managed) {   // lib/vorbisenc.c:890-901
                 const long long *r = mode.i64("bi/rates");
                 const double *d = mode.f64("bi/floats");
