@@ -101,3 +101,9 @@ def test_managed_other_classes_from_pcm(oracle, cuda, ch, rate, bitrate, secs):
 ])
 def test_other_managed_classes_from_pcm(oracle, cuda, ch, rate, bitrate):
     frontend_vs_oracle(oracle, cuda, ch, rate, None, NS=4, seconds=1.7, bitrate=bitrate)
+
+
+def test_loop_over_the_blobs_gives_the_same(oracle, cuda, monkeypatch):
+    """VBM_MANAGED_WIDE=0: the round-2 form of the back half (one pass per packetblob) is kept for A/B; same packets"""
+    monkeypatch.setenv("VBM_MANAGED_WIDE", "0")
+    frontend_vs_oracle(oracle, cuda, 2, 44100, None, NS=4, seconds=1.7, bitrate=(144000, 128000, 112000))

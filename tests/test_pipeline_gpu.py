@@ -108,6 +108,14 @@ def test_stereo_q5_stage_and_packet_parity(oracle, cuda):
     assert modes == {0, 1, 2, 3}     # impulse, padding, transition and long blocks all occurred
 
 
+def test_noise_mask_ring_form(oracle, cuda, monkeypatch):
+    """VBM_NOISE_RING=1: the noise mask's sums in a 512-row ring with a scan wavefront beside the solves (opt-in: measured
+    slower) — same stage outputs and packets"""
+    monkeypatch.setenv("VBM_NOISE_RING", "1")
+    modes, nsteps = run_case(oracle, cuda, 2, 44100, 0.5, nstreams=24, seconds=2.0)
+    assert 3 in modes
+
+
 def test_stereo_q1_packet_parity(oracle, cuda):
     # q0.1: live noise normalisation (normal_start 16/128) and the 128x4 short floor
     run_case(oracle, cuda, 2, 44100, 0.1, nstreams=8, seconds=3.0)

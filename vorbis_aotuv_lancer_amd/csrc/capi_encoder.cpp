@@ -527,7 +527,8 @@ static void configure(vbm_encoder *e, vbm_batch &b, int block_mode, int nsb, con
         // opt-in (VBM_NOISE_RING=1): measured slower than the plain form — alone 0.93 ms against 0.73, from PCM 5.10 ms per
         // step against 4.51 (profiles/r03/README.md): a barrier per 64-bin chunk puts the scan's chunk on every iteration's
         // critical path, and seven workgroups of five wavefronts per CU do not make up for it
-        static const int ring = getenv("VBM_NOISE_RING") ? atoi(getenv("VBM_NOISE_RING")) : 0;
+        const char *rv = getenv("VBM_NOISE_RING");      // (read per call: the tests switch it inside one process)
+        const int ring = rv ? atoi(rv) : 0;
         b.noise_ring = ring && s->psy[block_mode].hy_ring;
     }
     {
@@ -630,7 +631,8 @@ static int managed_front(const vbm_batch &v, hipStream_t q)
 // touches state carried from block to block: bm_avg_reservoir / bm_minmax_reservoir / bm_avgfloat of the streams)
 static int managed_back(const vbm_batch &v, uint8_t *d_packets, hipStream_t q, const std::function<int()> &before_choose = nullptr)
 {
-    static const int wide = getenv("VBM_MANAGED_WIDE") ? atoi(getenv("VBM_MANAGED_WIDE")) : 1;
+    const char *wv = getenv("VBM_MANAGED_WIDE");        // (read per call: the tests switch it inside one process)
+    const int wide = wv ? atoi(wv) : 1;
     if (wide) {
         // all fifteen packetblobs per launch (blob = blockIdx.z); the blobs' coupling passes form a chain through the npeak
         // rows (lib/mapping0.c:1249-1260, lib/psy.c:5100-5108): the lane-per-bin kernel walks them in a loop of its own, the
