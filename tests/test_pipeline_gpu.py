@@ -116,6 +116,14 @@ def test_noise_mask_ring_form(oracle, cuda, monkeypatch):
     assert 3 in modes
 
 
+def test_fused_packet_assembly(oracle, cuda, monkeypatch):
+    """VBM_PACK_FUSED=1: one wavefront per stream-block builds the packet with the codewords in LDS (opt-in: 0.2 GB of
+    traffic instead of 0.9, slower in the pipeline) — same packets, all block types"""
+    monkeypatch.setenv("VBM_PACK_FUSED", "1")
+    modes, nsteps = run_case(oracle, cuda, 2, 44100, 0.5, nstreams=24, seconds=2.0)
+    assert 3 in modes
+
+
 def test_stereo_q1_packet_parity(oracle, cuda):
     # q0.1: live noise normalisation (normal_start 16/128) and the 128x4 short floor
     run_case(oracle, cuda, 2, 44100, 0.1, nstreams=8, seconds=3.0)

@@ -563,7 +563,8 @@ static void configure(vbm_encoder *e, vbm_batch &b, int block_mode, int nsb, con
         // lane-per-block kernels holds 8 KB for 64 of them — which keeps the other half of the pipeline off the CUs:
         // pack alone 0.80 ms against 0.64, from PCM 4.81 ms per step against 4.67.
         {
-            static const int want = getenv("VBM_PACK_FUSED") ? atoi(getenv("VBM_PACK_FUSED")) : 0;
+            const char *pf = getenv("VBM_PACK_FUSED");      // (read per call: the tests switch it inside one process)
+            const int want = pf ? atoi(pf) : 0;
             const vbm_residue &r0 = s->residue[m.residuesubmap[0]];
             const int nbch = e->ch;
             b.pack_fused = want && !s->managed && m.submaps == 1 && b.couple_fast &&
