@@ -102,7 +102,7 @@ template <int TM_NB>
 __global__ __launch_bounds__(TM_NB * 32) void k_tonemask(vbm_batch b, const int phases, const int runin)   // phases: timing experiments (31 = all)
 {
     constexpr int TM_THREADS = TM_NB * 32;
-    extern __shared__ int tm_lds[];
+    extern __shared__ __align__(16) int tm_lds[];
     __shared__ float s_att[TM_NB], s_dboff[TM_NB];
     __shared__ unsigned long long s_alive[TM_NB][TM_CHUNKS];
     const vbm_psy *p = &b.setup->psy[b.block_mode];
@@ -184,24 +184,40 @@ __global__ __launch_bounds__(TM_NB * 32) void k_tonemask(vbm_batch b, const int 
     __syncthreads();
 
     // ---- compare: GE bit k-1 = !(s[j] < s[j-k]), LE bit d-1 = (s[j] <= s[j-d]) ---------------------------------
-    int cblk = 0, cj = tid;
-    if (phases & 2) for (int item = tid; item < nblk * tn; item += TM_THREADS, cj += TM_THREADS) {
-        while (cj >= tn) { cj -= tn; cblk++; }
-        const int blk = cblk, j = cj;
-        const float *sd = seedF + blk * tnp;
-        const float s = sd[j];
-        float o[7];
+    // A thread takes eight consecutive lines: their seeds and the seven before them are read once (15 LDS reads for
+    // 8 x 13 comparisons; a line at a time it was 8 reads and the index arithmetic per line: 44 M of the kernel's 209 M
+    // vector instructions per launch, rocprofv3 SQ_INSTS_VALU with the phase switched off), the eight results go out as
+    // one 16-byte store (the rows are 8-line aligned: glp is a multiple of 8, the row's base a multiple of 32 bytes).
+    if (phases & 2) {
+        const int ngrp = (tn + 7) >> 3;
+        int cblk = 0, cg = tid;
+        for (int item = tid; item < nblk * ngrp; item += TM_THREADS, cg += TM_THREADS) {
+            while (cg >= ngrp) { cg -= ngrp; cblk++; }
+            const int j0 = cg << 3;
+            const float *sd = seedF + cblk * tnp;
+            float w[15];                               // w[7 + u] = seed of line j0 + u, w[7 - k] = seed of line j0 - k
 #pragma unroll
-        for (int k = 1; k <= 7; k++) o[k - 1] = sd[(j - k >= 0) ? j - k : 0];
-        unsigned ge = 0, le = 0;
-#pragma unroll
-        for (int k = 1; k <= 7; k++) {
-            if (j - k >= 0) {
-                if (!(s < o[k - 1])) ge |= 1u << (k - 1);
-                if (k <= 6 && s <= o[k - 1]) le |= 1u << (k - 1);
+            for (int t = 0; t < 15; t++) {
+                int q = j0 - 7 + t;
+                q = q < 0 ? 0 : (q < tn ? q : tn - 1);
+                w[t] = sd[q];
             }
+            unsigned r[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int j = j0 + u;
+                unsigned ge = 0, le = 0;
+#pragma unroll
+                for (int k = 1; k <= 7; k++) {
+                    if (j - k >= 0) {
+                        if (!(w[7 + u] < w[7 + u - k])) ge |= 1u << (k - 1);
+                        if (k <= 6 && w[7 + u] <= w[7 + u - k]) le |= 1u << (k - 1);
+                    }
+                }
+                r[u >> 1] |= (ge | (le << 8)) << (16 * (u & 1));
+            }
+            *reinterpret_cast<uint4 *>(glS + cblk * glp + j0) = make_uint4(r[0], r[1], r[2], r[3]);
         }
-        glS[blk * glp + j] = (unsigned short)(ge | (le << 8));
     }
     __syncthreads();
 
