@@ -7,9 +7,10 @@
 //     logfft[(j+1)>>1] = scale_dB + .5f*todB(re^2+im^2)  + .345      (j = 1,3,..,n-3)
 //     local_ampmax     = min(0, max logfft)
 // Bit-identical to the scalar reference: the FFTPACK pass structure (factors applied last
-// to first, ping-pong between two buffers) and every butterfly expression are kept; only
-// the schedule changes — each pass's independent butterflies are spread over the 64 lanes,
-// the two ping-pong buffers live in LDS, twiddles (computed on the host with libm exactly
+// to first) and every butterfly expression are kept; only the schedule changes — each pass's
+// independent butterflies are spread over the 64 lanes, the block lives in LDS (round 3: ONE
+// buffer per wavefront, a pass reads all its inputs into registers before it writes — the
+// source's ping-pong between two buffers is kept for 4096-sample blocks only), twiddles (computed on the host with libm exactly
 // as drfti1 does, lib/smallft.c:5629-5640) are LDS-resident.  `+ .345` is a double add
 // rounded to float, as in the C source.
 #include <hip/hip_runtime.h>
@@ -125,6 +126,224 @@ __device__ __forceinline__ void radf2_pass(const float *cc, float *ch, const flo
 #undef CC
 }
 
+// ---- the same passes IN PLACE (round 3).  A pass is a permutation-with-arithmetic of the whole buffer: every lane first
+// reads the inputs of ALL its butterflies into registers (at most 40 floats for n = 2048), then computes and writes.  One
+// wavefront owns the buffer and its LDS instructions execute in order, so every read of the pass precedes every write:
+// no second buffer.  8 KB of LDS per 2048-sample block instead of 16: three workgroups of four wavefronts per CU instead
+// of two.  Every butterfly expression is the one above, operand for operand.
+template <int IDO, int L1>
+__device__ __forceinline__ void radf4_inplace(float *c, const float *wa1, const float *wa2, const float *wa3, int lane)
+{
+#define CC(i, k, j) c[(i) + IDO * ((k) + L1 * (j))]
+#define CH(i, j, k) c[(i) + IDO * ((j) + 4 * (k))]
+    constexpr int KI = (L1 + 63) / 64;
+    constexpr int PER_K = IDO > 2 ? IDO / 2 - 1 : 1;
+    constexpr int TOTAL = IDO > 2 ? L1 * PER_K : 0;
+    constexpr int TI = IDO > 2 ? (TOTAL + 63) / 64 : 1;
+    constexpr bool LAST = IDO >= 2 && !(IDO & 1);
+    float a[KI][4], z[KI][4], g[TI][8];
+    // ---- reads
+#pragma unroll
+    for (int q = 0; q < KI; q++) {
+        const int k = lane + 64 * q;
+        if (k < L1) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) a[q][j] = CC(0, k, j);
+            if (LAST)
+#pragma unroll
+                for (int j = 0; j < 4; j++) z[q][j] = CC(IDO - 1, k, j);
+        }
+    }
+    if (IDO > 2) {
+#pragma unroll
+        for (int q = 0; q < TI; q++) {
+            const int t = lane + 64 * q;
+            if (t < TOTAL) {
+                const int k = t / PER_K;
+                const int i = 2 + 2 * (t - k * PER_K);
+#pragma unroll
+                for (int j = 0; j < 4; j++) { g[q][2 * j] = CC(i - 1, k, j); g[q][2 * j + 1] = CC(i, k, j); }
+            }
+        }
+    }
+    wave_lds_sync();
+    // ---- butterflies and writes
+#pragma unroll
+    for (int q = 0; q < KI; q++) {
+        const int k = lane + 64 * q;
+        if (k < L1) {
+            float tr1 = a[q][1] + a[q][3];
+            float tr2 = a[q][0] + a[q][2];
+            CH(0, 0, k) = tr1 + tr2;
+            CH(IDO - 1, 3, k) = tr2 - tr1;
+            CH(IDO - 1, 1, k) = a[q][0] - a[q][2];
+            CH(0, 2, k) = a[q][3] - a[q][1];
+        }
+    }
+    if (IDO > 2) {
+#pragma unroll
+        for (int q = 0; q < TI; q++) {
+            const int t = lane + 64 * q;
+            if (t < TOTAL) {
+                const int k = t / PER_K;
+                const int i = 2 + 2 * (t - k * PER_K);
+                const int ic = IDO - i;
+                const float c0r = g[q][0], c0i = g[q][1], c1r = g[q][2], c1i = g[q][3], c2r = g[q][4], c2i = g[q][5],
+                            c3r = g[q][6], c3i = g[q][7];                 // CC(i-1,k,j), CC(i,k,j)
+                float cr2 = wa1[i - 2] * c1r + wa1[i - 1] * c1i;
+                float ci2 = wa1[i - 2] * c1i - wa1[i - 1] * c1r;
+                float cr3 = wa2[i - 2] * c2r + wa2[i - 1] * c2i;
+                float ci3 = wa2[i - 2] * c2i - wa2[i - 1] * c2r;
+                float cr4 = wa3[i - 2] * c3r + wa3[i - 1] * c3i;
+                float ci4 = wa3[i - 2] * c3i - wa3[i - 1] * c3r;
+                float tr1 = cr2 + cr4, tr4 = cr4 - cr2;
+                float ti1 = ci2 + ci4, ti4 = ci2 - ci4;
+                float ti2 = c0i + ci3, ti3 = c0i - ci3;
+                float tr2 = c0r + cr3, tr3 = c0r - cr3;
+                CH(i - 1, 0, k) = tr1 + tr2;
+                CH(i, 0, k) = ti1 + ti2;
+                CH(ic - 1, 1, k) = tr3 - ti4;
+                CH(ic, 1, k) = tr4 - ti3;
+                CH(i - 1, 2, k) = ti4 + tr3;
+                CH(i, 2, k) = tr4 + ti3;
+                CH(ic - 1, 3, k) = tr2 - tr1;
+                CH(ic, 3, k) = ti1 - ti2;
+            }
+        }
+    }
+    if (LAST) {
+        constexpr float hsqt2 = .70710678118654752f;
+#pragma unroll
+        for (int q = 0; q < KI; q++) {
+            const int k = lane + 64 * q;
+            if (k < L1) {
+                float ti1 = -hsqt2 * (z[q][1] + z[q][3]);
+                float tr1 = hsqt2 * (z[q][1] - z[q][3]);
+                CH(IDO - 1, 0, k) = tr1 + z[q][0];
+                CH(IDO - 1, 2, k) = z[q][0] - tr1;
+                CH(0, 1, k) = ti1 - z[q][2];
+                CH(0, 3, k) = ti1 + z[q][2];
+            }
+        }
+    }
+#undef CH
+#undef CC
+}
+
+template <int IDO, int L1>
+__device__ __forceinline__ void radf2_inplace(float *c, const float *wa1, int lane)
+{
+#define CC(i, k, j) c[(i) + IDO * ((k) + L1 * (j))]
+#define CH(i, j, k) c[(i) + IDO * ((j) + 2 * (k))]
+    constexpr int KI = (L1 + 63) / 64;
+    constexpr int PER_K = IDO > 2 ? IDO / 2 - 1 : 1;
+    constexpr int TOTAL = IDO > 2 ? L1 * PER_K : 0;
+    constexpr int TI = IDO > 2 ? (TOTAL + 63) / 64 : 1;
+    constexpr bool LAST = IDO >= 2 && !(IDO & 1);
+    float a[KI][2], z[KI][2], g[TI][4];
+#pragma unroll
+    for (int q = 0; q < KI; q++) {
+        const int k = lane + 64 * q;
+        if (k < L1) {
+            a[q][0] = CC(0, k, 0); a[q][1] = CC(0, k, 1);
+            if (LAST) { z[q][0] = CC(IDO - 1, k, 0); z[q][1] = CC(IDO - 1, k, 1); }
+        }
+    }
+    if (IDO > 2) {
+#pragma unroll
+        for (int q = 0; q < TI; q++) {
+            const int t = lane + 64 * q;
+            if (t < TOTAL) {
+                const int k = t / PER_K;
+                const int i = 2 + 2 * (t - k * PER_K);
+                g[q][0] = CC(i - 1, k, 0); g[q][1] = CC(i, k, 0); g[q][2] = CC(i - 1, k, 1); g[q][3] = CC(i, k, 1);
+            }
+        }
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int q = 0; q < KI; q++) {
+        const int k = lane + 64 * q;
+        if (k < L1) {
+            CH(0, 0, k) = a[q][0] + a[q][1];
+            CH(IDO - 1, 1, k) = a[q][0] - a[q][1];
+        }
+    }
+    if (IDO > 2) {
+#pragma unroll
+        for (int q = 0; q < TI; q++) {
+            const int t = lane + 64 * q;
+            if (t < TOTAL) {
+                const int k = t / PER_K;
+                const int i = 2 + 2 * (t - k * PER_K);
+                const int ic = IDO - i;
+                float tr2 = wa1[i - 2] * g[q][2] + wa1[i - 1] * g[q][3];
+                float ti2 = wa1[i - 2] * g[q][3] - wa1[i - 1] * g[q][2];
+                CH(i, 0, k) = g[q][1] + ti2;
+                CH(ic, 1, k) = ti2 - g[q][1];
+                CH(i - 1, 0, k) = g[q][0] + tr2;
+                CH(ic - 1, 1, k) = g[q][0] - tr2;
+            }
+        }
+    }
+    if (LAST) {
+#pragma unroll
+        for (int q = 0; q < KI; q++) {
+            const int k = lane + 64 * q;
+            if (k < L1) {
+                CH(0, 1, k) = -z[q][1];
+                CH(IDO - 1, 0, k) = z[q][0];
+            }
+        }
+    }
+#undef CH
+#undef CC
+}
+
+// the pass sequences of fft_forward<N> below, in place (result in c)
+template <int N>
+__device__ __forceinline__ void fft_forward_inplace(float *c, const float *wa, int lane);
+
+template <>
+__device__ __forceinline__ void fft_forward_inplace<2048>(float *c, const float *wa, int lane)
+{
+    radf4_inplace<1, 512>(c, wa + 2044, wa + 2045, wa + 2046, lane);  wave_lds_sync();
+    radf4_inplace<4, 128>(c, wa + 2032, wa + 2036, wa + 2040, lane);  wave_lds_sync();
+    radf4_inplace<16, 32>(c, wa + 1984, wa + 2000, wa + 2016, lane);  wave_lds_sync();
+    radf4_inplace<64, 8>(c, wa + 1792, wa + 1856, wa + 1920, lane);   wave_lds_sync();
+    radf4_inplace<256, 2>(c, wa + 1024, wa + 1280, wa + 1536, lane);  wave_lds_sync();
+    radf2_inplace<1024, 1>(c, wa + 0, lane);                          wave_lds_sync();
+}
+
+template <>
+__device__ __forceinline__ void fft_forward_inplace<1024>(float *c, const float *wa, int lane)
+{
+    radf4_inplace<1, 256>(c, wa + 1020, wa + 1021, wa + 1022, lane);  wave_lds_sync();
+    radf4_inplace<4, 64>(c, wa + 1008, wa + 1012, wa + 1016, lane);   wave_lds_sync();
+    radf4_inplace<16, 16>(c, wa + 960, wa + 976, wa + 992, lane);     wave_lds_sync();
+    radf4_inplace<64, 4>(c, wa + 768, wa + 832, wa + 896, lane);      wave_lds_sync();
+    radf4_inplace<256, 1>(c, wa + 0, wa + 256, wa + 512, lane);       wave_lds_sync();
+}
+
+template <>
+__device__ __forceinline__ void fft_forward_inplace<512>(float *c, const float *wa, int lane)
+{
+    radf4_inplace<1, 128>(c, wa + 508, wa + 509, wa + 510, lane);     wave_lds_sync();
+    radf4_inplace<4, 32>(c, wa + 496, wa + 500, wa + 504, lane);      wave_lds_sync();
+    radf4_inplace<16, 8>(c, wa + 448, wa + 464, wa + 480, lane);      wave_lds_sync();
+    radf4_inplace<64, 2>(c, wa + 256, wa + 320, wa + 384, lane);      wave_lds_sync();
+    radf2_inplace<256, 1>(c, wa + 0, lane);                           wave_lds_sync();
+}
+
+template <>
+__device__ __forceinline__ void fft_forward_inplace<256>(float *c, const float *wa, int lane)
+{
+    radf4_inplace<1, 64>(c, wa + 252, wa + 253, wa + 254, lane);      wave_lds_sync();
+    radf4_inplace<4, 16>(c, wa + 240, wa + 244, wa + 248, lane);      wave_lds_sync();
+    radf4_inplace<16, 4>(c, wa + 192, wa + 208, wa + 224, lane);      wave_lds_sync();
+    radf4_inplace<64, 1>(c, wa + 0, wa + 64, wa + 128, lane);         wave_lds_sync();
+}
+
 // drftf1 (lib/smallft.c:6111-6170) unrolled for the two factorisations in use:
 //   n = 2048: ifac = {2,4,4,4,4,4}  ->  passes (ip,l1,ido) = (4,512,1) (4,128,4) (4,32,16) (4,8,64) (4,2,256) (2,1,1024)
 //   n = 256 : ifac = {4,4,4,4}      ->  passes (4,64,1) (4,16,4) (4,4,16) (4,1,64)
@@ -227,9 +446,26 @@ template <int N> struct fft_result_in_ch { static constexpr bool value = (N == 1
 
 // waves per workgroup: two LDS buffers of N floats per wave; 4096-sample blocks leave room for two waves
 template <int N> struct fft_waves { static constexpr int value = (N == 4096) ? 2 : WAVES_PER_WG; };
+// in place (one LDS buffer per wave) for every size but 4096 (64 floats per lane and pass would not stay in registers)
+template <int N> struct fft_inplace { static constexpr bool value = (N != 4096); };
+template <int N, bool IP> struct fft_run;
+template <int N> struct fft_run<N, true> {
+    static __device__ __forceinline__ const float *go(float *c, float *, const float *wa, int lane)
+    {
+        fft_forward_inplace<N>(c, wa, lane);
+        return c;
+    }
+};
+template <int N> struct fft_run<N, false> {
+    static __device__ __forceinline__ const float *go(float *c, float *ch, const float *wa, int lane)
+    {
+        fft_forward<N>(c, ch, wa, lane);
+        return fft_result_in_ch<N>::value ? ch : c;
+    }
+};
 
 template <int N>
-__global__ __launch_bounds__(64 * fft_waves<N>::value)
+__global__ __launch_bounds__(64 * fft_waves<N>::value) __attribute__((amdgpu_waves_per_eu(N == 4096 ? 1 : 3)))
 void k_window_fft_log(const float *__restrict__ pcm, float *__restrict__ logfft,
                       float *__restrict__ local_ampmax, const uint8_t *__restrict__ wflags,
                       const float *__restrict__ wa_g,      // FFTPACK twiddles, N floats (trigcache + N)
@@ -244,7 +480,8 @@ void k_window_fft_log(const float *__restrict__ pcm, float *__restrict__ logfft,
     __shared__ __attribute__((aligned(16))) float s_win[N / 2];
     __shared__ __attribute__((aligned(16))) float s_wshort[N / 4];   // rising half-window of a short block (<= N/2 long)
     constexpr int NW = fft_waves<N>::value;
-    __shared__ __attribute__((aligned(16))) float s_buf[NW][2][N];
+    constexpr int NBUF = fft_inplace<N>::value ? 1 : 2;
+    __shared__ __attribute__((aligned(16))) float s_buf[NW][NBUF][N];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -256,7 +493,7 @@ void k_window_fft_log(const float *__restrict__ pcm, float *__restrict__ logfft,
     __syncthreads();
 
     float *c = s_buf[wave][0];
-    float *ch = s_buf[wave][1];
+    float *ch = s_buf[wave][NBUF - 1];
     const float scale = 4.f / N;
     const float scale_dB = (float)((double)todB(scale) + .345);  // lib/mapping0.c:795
 
@@ -294,8 +531,7 @@ void k_window_fft_log(const float *__restrict__ pcm, float *__restrict__ logfft,
         }
         wave_lds_sync();
 
-        fft_forward<N>(c, ch, s_wa, lane);
-        const float *spec = fft_result_in_ch<N>::value ? ch : c;
+        const float *spec = fft_run<N, fft_inplace<N>::value>::go(c, ch, s_wa, lane);
 
         // ---- log power spectrum + block maximum (lib/mapping0.c:848-888) -----------------
         float *o = logfft + blk * (N / 2);
@@ -336,7 +572,8 @@ extern "C" int vbm_launch_window_fft_log(const float *d_pcm, float *d_logfft, fl
     if (n != 4096 && n != 2048 && n != 1024 && n != 512 && n != 256) return -1;
     const int nw = (n == 4096) ? 2 : WAVES_PER_WG;
     long wgs = (nblocks + nw - 1) / nw;
-    if (wgs > 256 * 2) wgs = 256 * 2;
+    const long per_cu = (n == 4096) ? 1 : (n == 2048) ? 3 : 4;     // workgroups a CU holds (LDS: tables + a buffer per wave)
+    if (wgs > 256 * per_cu) wgs = 256 * per_cu;
     dim3 grid((unsigned)wgs), block(64 * nw);
 #define LAUNCH_FFT(NN)                                                                                              \
     hipLaunchKernelGGL(k_window_fft_log<NN>, grid, block, 0, stream, d_pcm, d_logfft, d_local_ampmax, d_wflags, d_wa, \
